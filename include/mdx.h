@@ -1,0 +1,218 @@
+/*
+ * mdx.h -- C-ABI of libmdx, the MI355X (gfx950) trajectory-analysis kernels.
+ *
+ * The reference package (MDSuite) has no FFI: its calculators call TensorFlow /
+ * TensorFlow-Probability ops from Python.  Each entry point below replaces the
+ * numerical body of one reference function; the comment above it names that
+ * function (paths relative to the reference checkout).  Everything is plain C:
+ * pointers, sizes, status codes.  No torch / numpy types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns MDX_OK (0) or a negative MDX_ERR_* code; the text of
+ *     the last error on the calling thread is returned by mdx_last_error();
+ *   - HIP errors never abort the process, they come back as MDX_ERR_DEVICE;
+ *   - "location" arguments say where a data pointer lives: MDX_HOST (the library
+ *     stages it through device memory itself) or MDX_DEVICE (a pointer obtained
+ *     from mdx_malloc, or any other hipMalloc'ed pointer on the current device);
+ *   - the caller owns every buffer it passes in for the duration of the call;
+ *     the library owns device memory behind opaque handles;
+ *   - trajectory arrays use the reference's in-memory layout
+ *     [n_atoms][n_frames][n_dims], C-contiguous ("atom-major"), as yielded by
+ *     TrajectoryCalculator.get_batch_dataset
+ *     (mdsuite/calculators/trajectory_calculator.py:346-363);
+ *   - one handle / one device is driven by one host thread at a time; all work of
+ *     a thread is issued on one HIP stream owned by the library (per device).
+ */
+#ifndef MDX_H
+#define MDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_OK 0
+#define MDX_ERR_INVALID_ARGUMENT (-1)
+#define MDX_ERR_DEVICE (-2)
+#define MDX_ERR_OUT_OF_MEMORY (-3)
+#define MDX_ERR_STATE (-4)
+
+#define MDX_HOST 0
+#define MDX_DEVICE 1
+
+#define MDX_F32 0
+#define MDX_F64 1
+
+/* ------------------------------------------------------------------ runtime */
+
+/* Library version as major*10000 + minor*100 + patch. */
+int mdx_version(void);
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *mdx_last_error(void);
+/* Number of visible HIP devices. */
+int mdx_device_count(int *count);
+/* Select the device used by the calling thread (default 0). */
+int mdx_set_device(int device);
+/* Name, compute-unit count and HBM size of the current device. */
+int mdx_device_info(char *name, size_t name_len, int *compute_units,
+                    uint64_t *memory_bytes);
+/* Block until all work issued on the library stream of the current device is done. */
+int mdx_synchronize(void);
+
+/* Device memory for callers that keep a trajectory resident in HBM. */
+int mdx_malloc(void **dptr, size_t bytes);
+int mdx_free(void *dptr);
+int mdx_memcpy_h2d(void *dptr, const void *host, size_t bytes);
+int mdx_memcpy_d2h(void *host, const void *dptr, size_t bytes);
+int mdx_memset(void *dptr, int byte_value, size_t bytes);
+
+/* HIP events recorded on the library stream (the stream every kernel of this
+ * library is launched on), for timing kernels from the host side. */
+typedef struct mdx_event_s *mdx_event_t;
+int mdx_event_create(mdx_event_t *ev);
+int mdx_event_record(mdx_event_t ev);
+/* Waits for `stop`, then returns the time between the two events. */
+int mdx_event_elapsed_ms(mdx_event_t start, mdx_event_t stop, float *ms);
+int mdx_event_destroy(mdx_event_t ev);
+
+/* Fill a device array with a deterministic synthetic trajectory (bench only):
+ * element i gets lo + (hi-lo)*u(seed, i), u = 24-bit counter hash in [0,1). */
+int mdx_fill_uniform_f32(float *dptr, uint64_t n, uint64_t seed, float lo, float hi);
+
+/* ---------------------------------------------------------------------- RDF */
+/*
+ * Replaces the per-batch body of RadialDistributionFunction.run_calculator
+ * (mdsuite/calculators/radial_distribution_function.py:846-885): for every
+ * sampled frame, all pairs i<j of the species-concatenated atom list
+ * (get_partial_triu_indices, mdsuite/utils/linalg.py:102-122), minimum-image
+ * distance in float32 (get_dij :647-689, apply_minimum_image linalg.py:84-99),
+ * species-pair masks and cutoff (bin_minibatch :616-645, apply_system_cutoff
+ * linalg.py:125-136) and the fixed-width histogram of tf.histogram_fixed_width
+ * (CPU kernel rule: bin = min(int(double(d) / (double(cutoff - 0) / nbins)),
+ * nbins - 1)).  Counts are integers and bit-exact with that sequence of float32
+ * operations.
+ */
+typedef struct mdx_rdf_s *mdx_rdf_t;
+
+/* Reproduce the reference's strict species masks, which drop the first atom of
+ * every species from both pair roles (radial_distribution_function.py:637-638).
+ * Without this flag every atom takes part (the physically intended result). */
+#define MDX_RDF_STRICT_REFERENCE_MASKS 1u
+/* Use the kernel that performs the reference's float operations literally
+ * (IEEE divide, rint, sqrt, float64 bin divide) instead of the table-driven
+ * kernel that is proven equal to it; for validation. */
+#define MDX_RDF_LITERAL_KERNEL 2u
+
+/*
+ * n_per_species[s] atoms of species s, in the order the calculator concatenates
+ * them (_format_data :535-563).  box/cutoff are float32 exactly as the reference
+ * casts them (:450, :520-522).  Histogram keys are the species pairs (a,b), a<=b,
+ * in itertools.combinations_with_replacement order (:272-275).
+ */
+int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_species,
+                   const float box[3], float cutoff, int nbins, uint32_t flags);
+int mdx_rdf_destroy(mdx_rdf_t handle);
+/* Zero the accumulated histograms. */
+int mdx_rdf_reset(mdx_rdf_t handle);
+/* Number of species-pair keys = n_species*(n_species+1)/2. */
+int mdx_rdf_num_keys(mdx_rdf_t handle, int *n_keys);
+/* Number of atom-pair tiles one frame is cut into (the unit sharded over GPUs). */
+int mdx_rdf_num_tiles(mdx_rdf_t handle, int64_t *n_tiles);
+/*
+ * Add the pair histogram of `n_frames` frames.  species_pos[s] points at the
+ * positions of species s, [n_per_species[s]][frame_stride][3] of `dtype`
+ * (float64 input is rounded to float32 first, as tf.cast does, :561-563).
+ * frames[i] (host array, may be NULL for 0..n_frames-1) selects the frame index
+ * along the second axis, like the reference's loop_array
+ * (mdsuite/database/data_manager.py:195-203).  Only atom-pair tiles t with
+ * t % shard_count == shard_rank are evaluated, so that several GPUs can split
+ * one frame; pass 0, 1 for everything.  Asynchronous on the library stream.
+ */
+int mdx_rdf_accumulate(mdx_rdf_t handle, const void *const *species_pos, int dtype,
+                       int location, int64_t frame_stride, const int64_t *frames,
+                       int64_t n_frames, int shard_rank, int shard_count);
+/* Copy the histograms [n_keys][nbins] (uint64 counts) to the host; synchronises. */
+int mdx_rdf_read(mdx_rdf_t handle, uint64_t *hist);
+
+/* -------------------------------------------------------- atom reductions */
+/*
+ * out[t][c] (+)= sum_a w_a * x[a][t][c], accumulated in float64.
+ * Replaces IonicCurrent.transform_batch (mdsuite/transformations/ionic_current.py:48-58)
+ * and TranslationalDipoleMoment.transform_batch
+ * (mdsuite/transformations/translational_dipole_moment.py:52-62) for one species:
+ * x is [n_atoms][n_frames][k]; weights is NULL (every w_a = scalar_weight, the
+ * per-species charge of transformations.py:406-414) or a host array of n_atoms
+ * float64 multiplied by scalar_weight.  accumulate != 0 adds to `out` (the
+ * tf.add_n over species), else overwrites.  out is [n_frames][k] float64.
+ */
+int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_atoms,
+                          int64_t n_frames, int k, const double *weights,
+                          double scalar_weight, double *out, int out_location,
+                          int accumulate);
+/*
+ * out[t][c] (+)= sum_a stress[a][t][3+c], c = 0..2: MomentumFlux.transform_batch
+ * (mdsuite/transformations/momentum_flux.py:45-55).  stress is [n_atoms][n_frames][6].
+ */
+int mdx_momentum_flux(const void *stress, int dtype, int location, int64_t n_atoms,
+                      int64_t n_frames, double *out, int out_location,
+                      int accumulate);
+/*
+ * out[t][:] (+)= sum_a ((ke+pe)[a][t] * v[a][t][:] - S[a][t] . v[a][t]) with the
+ * symmetric stress in the order xx,yy,zz,xy,xz,yz: ThermalFlux.transform_batch
+ * (mdsuite/transformations/thermal_flux.py:51-92).  ke, pe are [n_atoms][n_frames][1].
+ */
+int mdx_thermal_flux(const void *stress, const void *vel, const void *ke,
+                     const void *pe, int dtype, int location, int64_t n_atoms,
+                     int64_t n_frames, double *out, int out_location,
+                     int accumulate);
+
+/* ------------------------------------------------- time-lag correlations */
+/*
+ * Windowed autocorrelation, the ensemble loop of the Green-Kubo calculators:
+ * for every window w in [win_begin, win_end) of one loaded batch
+ * (dictionary_generator, mdsuite/database/data_manager.py:309-339: window w is
+ * frames w*correlation_time ... + data_range), every series s and dim d:
+ *     y[i]   = x[s][w*correlation_time + tau[i]][d]           i = 0..n_tau-1
+ *     R[m]   = (1/(n_tau-m)) * sum_{n=0}^{n_tau-1-m} y[n]*y[n+m]
+ * which is tfp.stats.auto_correlation(normalize=False, center=False) as called
+ * in GreenKuboIonicConductivity.ensemble_operation
+ * (mdsuite/calculators/green_kubo_ionic_conductivity.py:188-206) and
+ * GreenKuboDiffusionCoefficients.ensemble_operation
+ * (mdsuite/calculators/green_kubo_self_diffusion_coefficients.py:179-206).
+ * Per window  c_w[m] = scale * sum_s sum_d R[m].
+ * Outputs (host arrays, all float64):
+ *   acf_sum[n_tau]        += sum_w c_w                     (the calculator's acf_array)
+ *   If time != NULL, the per-window running integrals
+ *       I_w = cumulative_trapezoid(c_w * integral_scale, x=time)  (n_tau-1 values)
+ *   are folded into streaming moments over windows:
+ *   integral_mean[n_tau-1], integral_m2[n_tau-1] (sum of squared deviations) of
+ *   the windows of THIS call; *n_windows = win_end - win_begin.  The caller merges
+ *   calls with the parallel-variance formula to obtain np.std(self.sigmas, axis=0).
+ * x is [n_series][n_frames][k]; float32 input is widened to float64 exactly.
+ */
+int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
+                    int64_t n_frames, int k, int64_t correlation_time,
+                    int64_t win_begin, int64_t win_end, const int32_t *tau,
+                    int n_tau, double scale, double integral_scale,
+                    const double *time, double *acf_sum, double *integral_mean,
+                    double *integral_m2, int64_t *n_windows);
+/*
+ * Windowed mean-square displacement, the ensemble loop of the Einstein
+ * calculators: msd_sum[i] += scale * sum_w sum_s sum_d
+ *      (x[s][w*ct + tau[i]][d] - x[s][w*ct][d])^2
+ * EinsteinDiffusionCoefficients.ensemble_operation
+ * (mdsuite/calculators/einstein_diffusion_coefficients.py:168-190) and
+ * EinsteinHelfandIonicConductivity.ensemble_operation
+ * (mdsuite/calculators/einstein_helfand_ionic_conductivity.py:165-181).
+ */
+int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
+                    int64_t n_frames, int k, int64_t correlation_time,
+                    int64_t win_begin, int64_t win_end, const int32_t *tau,
+                    int n_tau, double scale, double *msd_sum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H */

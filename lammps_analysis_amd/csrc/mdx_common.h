@@ -1,0 +1,91 @@
+// Internal helpers shared by the libmdx translation units: error reporting,
+// per-device stream, scoped device buffers.  Not part of the public C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mdx.h"
+
+namespace mdx {
+
+// Thread-local text of the last error, returned by mdx_last_error().
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+// The library stream of the current device (created on first use).
+int get_stream(hipStream_t *stream);
+
+#define MDX_HIP(call)                                                          \
+  do {                                                                         \
+    hipError_t mdx_err_ = (call);                                              \
+    if (mdx_err_ != hipSuccess)                                                \
+      return ::mdx::fail(mdx_err_ == hipErrorOutOfMemory ? MDX_ERR_OUT_OF_MEMORY \
+                                                        : MDX_ERR_DEVICE,      \
+                         "%s failed: %s (%s:%d)", #call,                       \
+                         hipGetErrorString(mdx_err_), __FILE__, __LINE__);     \
+  } while (0)
+
+#define MDX_TRY(call)                                                          \
+  do {                                                                         \
+    int mdx_rc_ = (call);                                                      \
+    if (mdx_rc_ != MDX_OK) return mdx_rc_;                                     \
+  } while (0)
+
+#define MDX_REQUIRE(cond, ...)                                                 \
+  do {                                                                         \
+    if (!(cond)) return ::mdx::fail(MDX_ERR_INVALID_ARGUMENT, __VA_ARGS__);    \
+  } while (0)
+
+// Device allocation freed when it leaves scope (after the caller synchronised).
+struct DeviceBuffer {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  ~DeviceBuffer() { release(); }
+  int alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&ptr, n);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return fail(e == hipErrorOutOfMemory ? MDX_ERR_OUT_OF_MEMORY : MDX_ERR_DEVICE,
+                  "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    return MDX_OK;
+  }
+  // Grow-only reuse: keeps the allocation when it is already large enough.
+  int reserve(size_t n) {
+    if (ptr != nullptr && bytes >= n) return MDX_OK;
+    return alloc(n);
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T *as() const {
+    return static_cast<T *>(ptr);
+  }
+};
+
+// Returns a device pointer for `src`: the pointer itself when it already lives on
+// the device, else a staged copy held by `staging` (async copy on `stream`).
+int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
+              hipStream_t stream, const void **dptr);
+
+inline size_t dtype_size(int dtype) { return dtype == MDX_F64 ? 8 : 4; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mdx

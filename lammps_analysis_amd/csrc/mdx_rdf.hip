@@ -1,0 +1,604 @@
+// Radial distribution function: pair-distance histogramming on gfx950.
+//
+// Data flow per call of mdx_rdf_accumulate:
+//   1. pack kernel: the reference layout [atoms][frames][3] (one array per
+//      species) is gathered into a frame-major structure-of-arrays image
+//      X[frame][component][slot] whose slots are grouped in tiles of 256 atoms,
+//      one species per tile, padded with NaN (a NaN coordinate can never pass the
+//      cutoff test, so padding needs no bounds checks in the pair loop);
+//   2. tile kernel: one 256-thread block per (tile pair, frame group).  Each lane
+//      keeps one i-atom in registers, the j-tile is staged in LDS and read as a
+//      broadcast, the species-pair histogram lives in LDS (ds_add_u32) and is
+//      flushed once per block with 64-bit global atomics.
+//
+// Two pair functions produce identical bins:
+//   literal : the reference's float32 operations one by one (IEEE divide, rint,
+//             separate multiply/subtract, (x*x+y*y)+z*z, IEEE sqrt, d < cutoff,
+//             float64 divide by the bin width, min, truncation);
+//   table   : the bin as a function of the float32 squared distance is monotone,
+//             so it is described exactly by one float32 threshold per bin edge,
+//             computed on the host with the literal operations.  The kernel takes
+//             an approximate bin from v_sqrt_f32 and corrects it by comparing
+//             against the two neighbouring thresholds; the minimum-image rint uses
+//             a reciprocal multiply and falls back to the IEEE divide whenever the
+//             quotient is too close to a rounding boundary to be trusted.
+//
+// This file must be compiled with -ffp-contract=off: a fused multiply-add in the
+// minimum-image or the squared-distance expression changes the rounding and
+// therefore the bins.
+#include <cmath>
+
+#include "mdx_common.h"
+
+using namespace mdx;
+
+namespace {
+
+constexpr int kTile = 256;          // atoms per tile == threads per block
+constexpr int kMaxFramesPerGroup = 64;
+
+struct TilePair {
+  int32_t tile_i;
+  int32_t tile_j;
+  int32_t key;
+  int32_t diagonal;  // 1: same tile on both sides, only j > i counts
+};
+
+struct RdfParams {
+  float box[3];
+  float inv_box[3];
+  float cutoff;        // float32 cutoff (literal kernel)
+  float s_cut;         // smallest float32 s with sqrtf(s) >= cutoff (table kernel)
+  float inv_step;      // float32(nbins / cutoff), approximate bin scale
+  double step;         // double(cutoff - 0.0f) / double(nbins)
+  int nbins;
+};
+
+// ---------------------------------------------------------------- pack kernel
+
+// Gathers one block of frames into X[frame][component][slot].
+// slot_species[slot] < 0 marks a padding slot.  Reads run along the frame axis
+// (contiguous in the source when the frame list is contiguous), writes along the
+// slot axis; the exchange goes through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void rdf_pack_kernel(
+    const void *const *__restrict__ species_ptr, const int32_t *__restrict__ slot_species,
+    const int32_t *__restrict__ slot_atom, const int64_t *__restrict__ frames,
+    int64_t frame_base, int64_t frame_stride, int n_frames, int64_t n_pad,
+    float *__restrict__ packed) {
+  constexpr int kSlots = 64;
+  constexpr int kFrames = 16;
+  __shared__ float sh[kSlots][kFrames * 3 + 1];
+  const int64_t slot0 = static_cast<int64_t>(blockIdx.x) * kSlots;
+  const int f0 = blockIdx.y * kFrames;
+  // read phase: (slot, frame, component) with frame*3+component fastest
+  for (int e = threadIdx.x; e < kSlots * kFrames * 3; e += blockDim.x) {
+    const int s = e / (kFrames * 3);
+    const int r = e - s * (kFrames * 3);
+    const int f = r / 3;
+    const int c = r - f * 3;
+    float v = __builtin_nanf("");
+    const int64_t slot = slot0 + s;
+    if (slot < n_pad && f0 + f < n_frames) {
+      const int sp = slot_species[slot];
+      if (sp >= 0) {
+        const int64_t frame =
+            frames ? frames[f0 + f] : (frame_base + f0 + f);
+        const T *src = static_cast<const T *>(species_ptr[sp]);
+        v = static_cast<float>(
+            src[(static_cast<int64_t>(slot_atom[slot]) * frame_stride + frame) * 3 + c]);
+      }
+    }
+    sh[s][r] = v;
+  }
+  __syncthreads();
+  // write phase: slot fastest
+  for (int e = threadIdx.x; e < kSlots * kFrames * 3; e += blockDim.x) {
+    const int r = e / kSlots;
+    const int s = e - r * kSlots;
+    const int f = r / 3;
+    const int c = r - f * 3;
+    const int64_t slot = slot0 + s;
+    if (slot < n_pad && f0 + f < n_frames) {
+      packed[(static_cast<int64_t>(f0 + f) * 3 + c) * n_pad + slot] = sh[s][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------- pair functions
+
+// The reference's sequence of float32 operations, literally.
+__device__ __forceinline__ void pair_literal(float xi, float yi, float zi, float4 pj,
+                                             const RdfParams &p, bool allowed,
+                                             uint32_t *hist) {
+  float rx = pj.x - xi;
+  float ry = pj.y - yi;
+  float rz = pj.z - zi;
+  rx = rx - rintf(rx / p.box[0]) * p.box[0];
+  ry = ry - rintf(ry / p.box[1]) * p.box[1];
+  rz = rz - rintf(rz / p.box[2]) * p.box[2];
+  const float s = (rx * rx + ry * ry) + rz * rz;
+  const float d = sqrtf(s);
+  if (allowed && d < p.cutoff) {
+    double q = static_cast<double>(d) / p.step;
+    q = fmin(q, static_cast<double>(p.nbins - 1));
+    atomicAdd(&hist[static_cast<int>(q)], 1u);
+  }
+}
+
+// rint(r / box) in float32, exactly as the IEEE divide would give it: the product
+// with the rounded reciprocal is within a few ulp of the true quotient, so its
+// nearest integer is the right one unless the quotient lies that close to a
+// half-integer; only then the divide is executed.
+__device__ __forceinline__ float exact_rint_quotient(float r, float box, float inv_box) {
+  const float q = r * inv_box;
+  float n = rintf(q);
+  const float dist = fabsf(fabsf(q - n) - 0.5f);
+  if (__builtin_expect(dist <= fabsf(q) * 0x1p-20f + 0x1p-30f, 0)) {
+    n = rintf(r / box);
+  }
+  return n;
+}
+
+// Table-driven equivalent of pair_literal.  thresholds[k], k = 0..nbins, is the
+// smallest float32 squared distance that falls into bin >= k (thresholds[0] = 0,
+// thresholds[nbins] = +inf); s_cut is the smallest squared distance that fails
+// d < cutoff.
+__device__ __forceinline__ void pair_table(float xi, float yi, float zi, float4 pj,
+                                           const RdfParams &p,
+                                           const float *__restrict__ thresholds,
+                                           bool allowed, uint32_t *hist) {
+  float rx = pj.x - xi;
+  float ry = pj.y - yi;
+  float rz = pj.z - zi;
+  rx = rx - exact_rint_quotient(rx, p.box[0], p.inv_box[0]) * p.box[0];
+  ry = ry - exact_rint_quotient(ry, p.box[1], p.inv_box[1]) * p.box[1];
+  rz = rz - exact_rint_quotient(rz, p.box[2], p.inv_box[2]) * p.box[2];
+  const float s = (rx * rx + ry * ry) + rz * rz;
+  if (allowed && s < p.s_cut) {
+    int b = static_cast<int>(__builtin_amdgcn_sqrtf(s) * p.inv_step);
+    b = min(b, p.nbins - 1);
+    // the estimate is off by at most one bin; the thresholds decide
+    const float lo = thresholds[b];
+    const float hi = thresholds[b + 1];
+    b += (s >= hi) ? 1 : 0;
+    b -= (s < lo) ? 1 : 0;
+    atomicAdd(&hist[b], 1u);
+  }
+}
+
+// ---------------------------------------------------------------- tile kernel
+
+// LDS layout: uint32 hist[nbins_pad] | float thresholds[nbins_pad + 1 (+pad)] (table
+// kernel only) | float4 tile[kTile].
+template <bool kLiteral>
+__global__ __launch_bounds__(kTile) void rdf_tile_kernel(
+    const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_group,
+    const TilePair *__restrict__ pairs, RdfParams p,
+    const float *__restrict__ g_thresholds, int lds_hist_words, int lds_thr_words,
+    unsigned long long *__restrict__ g_hist) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
+  float *thr = reinterpret_cast<float *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words));
+  float4 *tile = reinterpret_cast<float4 *>(
+      lds_raw + 4 * static_cast<size_t>(lds_hist_words + lds_thr_words));
+
+  const int tid = threadIdx.x;
+  const TilePair tp = pairs[blockIdx.x];
+  const int f_begin = blockIdx.y * frames_per_group;
+  const int f_end = min(n_frames, f_begin + frames_per_group);
+
+  for (int b = tid; b < p.nbins; b += kTile) hist[b] = 0u;
+  if (!kLiteral) {
+    for (int b = tid; b <= p.nbins; b += kTile) thr[b] = g_thresholds[b];
+  }
+
+  const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
+  const int64_t slot_j = static_cast<int64_t>(tp.tile_j) * kTile + tid;
+  // In a diagonal tile lane t only pairs with j > t: a wave can skip every j that
+  // is not above its first lane.
+  const int j_start = tp.diagonal ? ((tid & ~63) + 1) : 0;
+
+  for (int f = f_begin; f < f_end; ++f) {
+    const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
+    const float xi = X[slot_i];
+    const float yi = X[n_pad + slot_i];
+    const float zi = X[2 * n_pad + slot_i];
+    const float4 mine = make_float4(X[slot_j], X[n_pad + slot_j], X[2 * n_pad + slot_j], 0.0f);
+    __syncthreads();  // previous frame's tile reads are complete (and LDS init)
+    tile[tid] = mine;
+    __syncthreads();
+#pragma unroll 4
+    for (int j = j_start; j < kTile; ++j) {
+      const float4 pj = tile[j];
+      const bool allowed = !tp.diagonal || (j > tid);
+      if (kLiteral) {
+        pair_literal(xi, yi, zi, pj, p, allowed, hist);
+      } else {
+        pair_table(xi, yi, zi, pj, p, thr, allowed, hist);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long *out = g_hist + static_cast<int64_t>(tp.key) * p.nbins;
+  for (int b = tid; b < p.nbins; b += kTile) {
+    const uint32_t v = hist[b];
+    if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
+  }
+}
+
+// --------------------------------------------------- host-side threshold table
+
+inline uint32_t float_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+inline float bits_float(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// Literal bin of a non-negative float32 squared distance; nbins means "outside
+// the cutoff".  Monotone non-decreasing in s because sqrtf, the float64 divide,
+// min and the truncation all are.
+inline int literal_bin_of_s(float s, float cutoff, double step, int nbins) {
+  volatile float d = sqrtf(s);
+  if (!(d < cutoff)) return nbins;
+  double q = static_cast<double>(d) / step;
+  const double top = static_cast<double>(nbins - 1);
+  if (q > top) q = top;
+  return static_cast<int>(q);
+}
+
+// Smallest non-negative float32 s (by bit pattern order, which is value order for
+// non-negative floats) with literal_bin_of_s(s) >= k; +inf bit pattern if none.
+inline float first_s_reaching(int k, float cutoff, double step, int nbins) {
+  uint32_t lo = 0u;            // candidate range over bit patterns [0, +inf]
+  uint32_t hi = 0x7F800000u;   // +inf: sqrtf(inf) = inf, not < cutoff -> nbins >= k
+  if (literal_bin_of_s(bits_float(lo), cutoff, step, nbins) >= k) return bits_float(lo);
+  while (hi - lo > 1u) {
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    if (literal_bin_of_s(bits_float(mid), cutoff, step, nbins) >= k)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return bits_float(hi);
+}
+
+}  // namespace
+
+struct mdx_rdf_s {
+  int device = 0;
+  int n_species = 0;
+  int n_keys = 0;
+  uint32_t flags = 0;
+  RdfParams params{};
+  std::vector<int64_t> n_per_species;
+  std::vector<TilePair> pairs;
+  int64_t n_tiles = 0;  // atom tiles
+  int64_t n_pad = 0;    // slots
+  int lds_hist_words = 0;
+  int lds_thr_words = 0;
+  size_t lds_bytes = 0;
+  DeviceBuffer d_pairs, d_pairs_shard, d_hist, d_thresholds, d_slot_species, d_slot_atom;
+  DeviceBuffer d_species_ptr, d_frames, d_packed;
+  int shard_rank = 0, shard_count = 1;
+  int64_t n_pairs_shard = 0;
+  std::vector<const void *> uploaded_ptrs;  // content of d_species_ptr
+};
+
+namespace {
+
+int upload_shard(mdx_rdf_s *h, int rank, int count, hipStream_t stream) {
+  if (h->d_pairs_shard.ptr != nullptr && h->shard_rank == rank && h->shard_count == count)
+    return MDX_OK;
+  std::vector<TilePair> mine;
+  for (size_t t = 0; t < h->pairs.size(); ++t) {
+    if (static_cast<int64_t>(t) % count == rank) mine.push_back(h->pairs[t]);
+  }
+  MDX_HIP(hipStreamSynchronize(stream));
+  MDX_TRY(h->d_pairs_shard.alloc(mine.size() * sizeof(TilePair) + 16));
+  if (!mine.empty()) {
+    MDX_HIP(hipMemcpy(h->d_pairs_shard.ptr, mine.data(), mine.size() * sizeof(TilePair),
+                      hipMemcpyHostToDevice));
+  }
+  h->shard_rank = rank;
+  h->shard_count = count;
+  h->n_pairs_shard = static_cast<int64_t>(mine.size());
+  return MDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_species,
+                   const float box[3], float cutoff, int nbins, uint32_t flags) {
+  MDX_REQUIRE(handle != nullptr, "handle is null");
+  *handle = nullptr;
+  MDX_REQUIRE(n_species >= 1 && n_species <= 1024, "n_species out of range");
+  MDX_REQUIRE(n_per_species != nullptr && box != nullptr, "null argument");
+  MDX_REQUIRE(nbins >= 1, "nbins must be positive");
+  MDX_REQUIRE(cutoff > 0.0f && std::isfinite(cutoff), "cutoff must be positive and finite");
+  for (int c = 0; c < 3; ++c)
+    MDX_REQUIRE(box[c] > 0.0f && std::isfinite(box[c]), "box lengths must be positive");
+  for (int s = 0; s < n_species; ++s)
+    MDX_REQUIRE(n_per_species[s] >= 0 && n_per_species[s] < (int64_t(1) << 31),
+                "species size out of range");
+
+  mdx_rdf_s *h = new (std::nothrow) mdx_rdf_s;
+  if (!h) return fail(MDX_ERR_OUT_OF_MEMORY, "out of host memory");
+  struct Guard {
+    mdx_rdf_s *h;
+    ~Guard() { delete h; }
+  } guard{h};
+
+  MDX_HIP(hipGetDevice(&h->device));
+  h->n_species = n_species;
+  h->n_keys = n_species * (n_species + 1) / 2;
+  h->flags = flags;
+  h->n_per_species.assign(n_per_species, n_per_species + n_species);
+  RdfParams &p = h->params;
+  for (int c = 0; c < 3; ++c) {
+    p.box[c] = box[c];
+    p.inv_box[c] = 1.0f / box[c];
+  }
+  p.cutoff = cutoff;
+  p.nbins = nbins;
+  // tf.histogram_fixed_width: step = double(range[1] - range[0]) / double(nbins),
+  // with the subtraction done in float32.
+  const float width = cutoff - 0.0f;
+  p.step = static_cast<double>(width) / static_cast<double>(nbins);
+  p.inv_step = static_cast<float>(static_cast<double>(nbins) / static_cast<double>(width));
+
+  // slots: per species, the atoms that take part, padded to whole tiles
+  const bool strict = (flags & MDX_RDF_STRICT_REFERENCE_MASKS) != 0u;
+  std::vector<int32_t> slot_species, slot_atom;
+  std::vector<int64_t> tile_first(n_species), tile_count(n_species);
+  int64_t tiles = 0;
+  for (int s = 0; s < n_species; ++s) {
+    const int64_t first = strict ? 1 : 0;
+    const int64_t used = n_per_species[s] > first ? n_per_species[s] - first : 0;
+    const int64_t nt = ceil_div(used, kTile);
+    tile_first[s] = tiles;
+    tile_count[s] = nt;
+    for (int64_t t = 0; t < nt * kTile; ++t) {
+      if (t < used) {
+        slot_species.push_back(s);
+        slot_atom.push_back(static_cast<int32_t>(first + t));
+      } else {
+        slot_species.push_back(-1);
+        slot_atom.push_back(0);
+      }
+    }
+    tiles += nt;
+  }
+  h->n_tiles = tiles;
+  h->n_pad = tiles * kTile;
+
+  // tile pairs in key order (a,b), a <= b
+  int key = 0;
+  for (int a = 0; a < n_species; ++a) {
+    for (int b = a; b < n_species; ++b, ++key) {
+      for (int64_t ti = 0; ti < tile_count[a]; ++ti) {
+        const int64_t tj0 = (a == b) ? ti : 0;
+        for (int64_t tj = tj0; tj < tile_count[b]; ++tj) {
+          TilePair tp;
+          tp.tile_i = static_cast<int32_t>(tile_first[a] + ti);
+          tp.tile_j = static_cast<int32_t>(tile_first[b] + tj);
+          tp.key = key;
+          tp.diagonal = (a == b && ti == tj) ? 1 : 0;
+          h->pairs.push_back(tp);
+        }
+      }
+    }
+  }
+
+  // LDS budget
+  const bool literal = (flags & MDX_RDF_LITERAL_KERNEL) != 0u;
+  h->lds_hist_words = (nbins + 3) & ~3;
+  h->lds_thr_words = literal ? 0 : ((nbins + 1 + 3) & ~3);
+  h->lds_bytes = 4 * static_cast<size_t>(h->lds_hist_words + h->lds_thr_words) +
+                 sizeof(float4) * kTile;
+  if (h->lds_bytes > 160 * 1024)
+    return fail(MDX_ERR_INVALID_ARGUMENT,
+                "nbins=%d needs %zu bytes of LDS per workgroup, more than the 160 KiB of a "
+                "gfx950 compute unit",
+                nbins, h->lds_bytes);
+  if (literal) {
+    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_tile_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(h->lds_bytes)));
+  } else {
+    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_tile_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(h->lds_bytes)));
+  }
+
+  // device tables
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  MDX_TRY(h->d_hist.alloc(sizeof(uint64_t) * static_cast<size_t>(h->n_keys) * nbins));
+  MDX_HIP(hipMemsetAsync(h->d_hist.ptr, 0, h->d_hist.bytes, stream));
+  MDX_TRY(h->d_slot_species.alloc(sizeof(int32_t) * slot_species.size() + 16));
+  MDX_TRY(h->d_slot_atom.alloc(sizeof(int32_t) * slot_atom.size() + 16));
+  if (!slot_species.empty()) {
+    MDX_HIP(hipMemcpy(h->d_slot_species.ptr, slot_species.data(),
+                      sizeof(int32_t) * slot_species.size(), hipMemcpyHostToDevice));
+    MDX_HIP(hipMemcpy(h->d_slot_atom.ptr, slot_atom.data(),
+                      sizeof(int32_t) * slot_atom.size(), hipMemcpyHostToDevice));
+  }
+  MDX_TRY(h->d_species_ptr.alloc(sizeof(void *) * n_species));
+
+  // thresholds of the table kernel (also defines s_cut)
+  p.s_cut = first_s_reaching(nbins, cutoff, p.step, nbins);
+  if (!literal) {
+    std::vector<float> thr(static_cast<size_t>(nbins) + 1);
+    thr[0] = 0.0f;
+    for (int k = 1; k < nbins; ++k) thr[k] = first_s_reaching(k, cutoff, p.step, nbins);
+    thr[nbins] = bits_float(0x7F800000u);
+    MDX_TRY(h->d_thresholds.alloc(sizeof(float) * thr.size()));
+    MDX_HIP(hipMemcpy(h->d_thresholds.ptr, thr.data(), sizeof(float) * thr.size(),
+                      hipMemcpyHostToDevice));
+  }
+  MDX_HIP(hipStreamSynchronize(stream));
+
+  guard.h = nullptr;
+  *handle = h;
+  return MDX_OK;
+}
+
+int mdx_rdf_destroy(mdx_rdf_t handle) {
+  if (!handle) return MDX_OK;
+  hipStream_t stream;
+  if (get_stream(&stream) == MDX_OK) (void)hipStreamSynchronize(stream);
+  delete handle;
+  return MDX_OK;
+}
+
+int mdx_rdf_reset(mdx_rdf_t h) {
+  MDX_REQUIRE(h != nullptr, "handle is null");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  MDX_HIP(hipMemsetAsync(h->d_hist.ptr, 0, h->d_hist.bytes, stream));
+  return MDX_OK;
+}
+
+int mdx_rdf_num_keys(mdx_rdf_t h, int *n_keys) {
+  MDX_REQUIRE(h != nullptr && n_keys != nullptr, "null argument");
+  *n_keys = h->n_keys;
+  return MDX_OK;
+}
+
+int mdx_rdf_num_tiles(mdx_rdf_t h, int64_t *n_tiles) {
+  MDX_REQUIRE(h != nullptr && n_tiles != nullptr, "null argument");
+  *n_tiles = static_cast<int64_t>(h->pairs.size());
+  return MDX_OK;
+}
+
+int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
+                       int location, int64_t frame_stride, const int64_t *frames,
+                       int64_t n_frames, int shard_rank, int shard_count) {
+  MDX_REQUIRE(h != nullptr && species_pos != nullptr, "null argument");
+  MDX_REQUIRE(dtype == MDX_F32 || dtype == MDX_F64, "dtype must be MDX_F32 or MDX_F64");
+  MDX_REQUIRE(location == MDX_HOST || location == MDX_DEVICE, "bad location");
+  MDX_REQUIRE(n_frames >= 0 && frame_stride >= 0, "negative frame count");
+  MDX_REQUIRE(shard_count >= 1 && shard_rank >= 0 && shard_rank < shard_count,
+              "bad shard (rank %d of %d)", shard_rank, shard_count);
+  if (frames != nullptr) {
+    for (int64_t i = 0; i < n_frames; ++i)
+      MDX_REQUIRE(frames[i] >= 0 && frames[i] < frame_stride,
+                  "frame index %lld outside [0, %lld)", (long long)frames[i],
+                  (long long)frame_stride);
+  } else {
+    MDX_REQUIRE(n_frames <= frame_stride, "n_frames exceeds frame_stride");
+  }
+  if (n_frames == 0 || h->n_pad == 0) return MDX_OK;
+
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  MDX_TRY(upload_shard(h, shard_rank, shard_count, stream));
+
+  // species arrays on the device
+  std::vector<DeviceBuffer> staged(location == MDX_HOST ? h->n_species : 0);
+  std::vector<const void *> ptrs(h->n_species, nullptr);
+  const size_t elem = dtype_size(dtype);
+  for (int s = 0; s < h->n_species; ++s) {
+    if (h->n_per_species[s] == 0) continue;
+    MDX_REQUIRE(species_pos[s] != nullptr, "positions of species %d are null", s);
+    const size_t bytes =
+        static_cast<size_t>(h->n_per_species[s]) * frame_stride * 3 * elem;
+    if (location == MDX_HOST) {
+      MDX_TRY(to_device(species_pos[s], MDX_HOST, bytes, staged[s], stream, &ptrs[s]));
+    } else {
+      ptrs[s] = species_pos[s];
+    }
+  }
+  // the pointer table and frame list may still be in use by an earlier call
+  if (ptrs != h->uploaded_ptrs) {
+    MDX_HIP(hipStreamSynchronize(stream));
+    MDX_HIP(hipMemcpy(h->d_species_ptr.ptr, ptrs.data(), sizeof(void *) * h->n_species,
+                      hipMemcpyHostToDevice));
+    h->uploaded_ptrs = ptrs;
+  }
+  const int64_t *d_frames = nullptr;
+  if (frames != nullptr) {
+    MDX_HIP(hipStreamSynchronize(stream));
+    MDX_TRY(h->d_frames.reserve(sizeof(int64_t) * static_cast<size_t>(n_frames)));
+    MDX_HIP(hipMemcpy(h->d_frames.ptr, frames, sizeof(int64_t) * n_frames,
+                      hipMemcpyHostToDevice));
+    d_frames = h->d_frames.as<int64_t>();
+  }
+
+  // frames are processed in chunks bounded by the packed image size
+  const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
+  int64_t chunk = static_cast<int64_t>((size_t(1) << 30) / bytes_per_frame);
+  if (chunk < 1) chunk = 1;
+  if (chunk > n_frames) chunk = n_frames;
+  if (chunk > 32768) chunk = 32768;
+  MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(chunk)));
+
+  const bool literal = (h->flags & MDX_RDF_LITERAL_KERNEL) != 0u;
+  for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
+    const int nf = static_cast<int>(std::min<int64_t>(chunk, n_frames - f0));
+    dim3 pgrid(static_cast<unsigned>(ceil_div(h->n_pad, 64)),
+               static_cast<unsigned>(ceil_div(nf, 16)));
+    if (dtype == MDX_F32) {
+      hipLaunchKernelGGL(rdf_pack_kernel<float>, pgrid, dim3(256), 0, stream,
+                         h->d_species_ptr.as<const void *>(),
+                         h->d_slot_species.as<int32_t>(), h->d_slot_atom.as<int32_t>(),
+                         d_frames ? d_frames + f0 : nullptr, f0, frame_stride, nf, h->n_pad,
+                         h->d_packed.as<float>());
+    } else {
+      hipLaunchKernelGGL(rdf_pack_kernel<double>, pgrid, dim3(256), 0, stream,
+                         h->d_species_ptr.as<const void *>(),
+                         h->d_slot_species.as<int32_t>(), h->d_slot_atom.as<int32_t>(),
+                         d_frames ? d_frames + f0 : nullptr, f0, frame_stride, nf, h->n_pad,
+                         h->d_packed.as<float>());
+    }
+    MDX_HIP(hipGetLastError());
+    if (h->n_pairs_shard == 0) continue;
+    // frames per block: large enough to amortise the histogram flush, small
+    // enough to keep several thousand blocks in flight
+    int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 8192;
+    if (fpg < 1) fpg = 1;
+    if (fpg > kMaxFramesPerGroup) fpg = kMaxFramesPerGroup;
+    dim3 grid(static_cast<unsigned>(h->n_pairs_shard),
+              static_cast<unsigned>(ceil_div(nf, fpg)));
+    if (literal) {
+      hipLaunchKernelGGL(rdf_tile_kernel<true>, grid, dim3(kTile), h->lds_bytes, stream,
+                         h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
+                         h->d_pairs_shard.as<TilePair>(), h->params,
+                         static_cast<const float *>(nullptr), h->lds_hist_words,
+                         h->lds_thr_words, h->d_hist.as<unsigned long long>());
+    } else {
+      hipLaunchKernelGGL(rdf_tile_kernel<false>, grid, dim3(kTile), h->lds_bytes, stream,
+                         h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
+                         h->d_pairs_shard.as<TilePair>(), h->params,
+                         h->d_thresholds.as<float>(), h->lds_hist_words, h->lds_thr_words,
+                         h->d_hist.as<unsigned long long>());
+    }
+    MDX_HIP(hipGetLastError());
+  }
+  if (location == MDX_HOST) {
+    // staged copies are released when this function returns
+    MDX_HIP(hipStreamSynchronize(stream));
+  }
+  return MDX_OK;
+}
+
+int mdx_rdf_read(mdx_rdf_t h, uint64_t *hist) {
+  MDX_REQUIRE(h != nullptr && hist != nullptr, "null argument");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  MDX_HIP(hipMemcpyAsync(hist, h->d_hist.ptr,
+                         sizeof(uint64_t) * static_cast<size_t>(h->n_keys) * h->params.nbins,
+                         hipMemcpyDeviceToHost, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,364 @@
+// Per-frame reductions over atoms: the streaming stage that turns per-atom
+// trajectories [atoms][frames][k] into system series [frames][3] (ionic current,
+// translational dipole moment, momentum flux, thermal flux).
+//
+// These kernels are bound by HBM bandwidth: every input element is read once and
+// takes part in one multiply and one add.  A thread owns a few adjacent columns
+// (frame, component) and walks down the atom axis, so a wave reads 1 KiB of
+// contiguous memory per atom with eight independent loads in flight per lane.
+// The atom axis is cut into chunks that run as separate blocks; their float64
+// partial sums are combined by a second kernel in chunk order, so results do not
+// depend on scheduling.
+//
+// Compiled with -ffp-contract=off: products are rounded before they are added,
+// as in the reference's separate multiply and reduce_sum operations.
+#include "mdx_common.h"
+
+using namespace mdx;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 8;
+
+template <typename T, int VEC>
+struct VecLoad;
+template <>
+struct VecLoad<float, 4> {
+  static __device__ __forceinline__ void load(const float *p, double (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+template <>
+struct VecLoad<double, 2> {
+  static __device__ __forceinline__ void load(const double *p, double (&v)[2]) {
+    const double2 t = *reinterpret_cast<const double2 *>(p);
+    v[0] = t.x; v[1] = t.y;
+  }
+};
+template <typename T>
+struct VecLoad<T, 1> {
+  static __device__ __forceinline__ void load(const T *p, double (&v)[1]) {
+    v[0] = static_cast<double>(*p);
+  }
+};
+
+// partial[chunk][col] = sum over the chunk's atoms of w_a * x[a][col]
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void weighted_sum_kernel(
+    const T *__restrict__ x, const double *__restrict__ weights, double scalar,
+    int64_t n_atoms, int64_t row_len, int64_t atoms_per_chunk,
+    double *__restrict__ partial) {
+  const int64_t col = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
+  if (col >= row_len) return;
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  double acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+  const T *p = x + a0 * row_len + col;
+  int64_t a = a0;
+  for (; a + kUnroll <= a1; a += kUnroll) {
+    double vals[kUnroll][VEC];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) VecLoad<T, VEC>::load(p + u * row_len, vals[u]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const double w = weights ? weights[a + u] * scalar : scalar;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = acc[v] + w * vals[u][v];
+    }
+    p += kUnroll * row_len;
+  }
+  for (; a < a1; ++a) {
+    double vals[VEC];
+    VecLoad<T, VEC>::load(p, vals);
+    const double w = weights ? weights[a] * scalar : scalar;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = acc[v] + w * vals[v];
+    p += row_len;
+  }
+  double *dst = partial + static_cast<int64_t>(blockIdx.y) * row_len + col;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) dst[v] = acc[v];
+}
+
+// partial[chunk][t*3+c] = sum over the chunk's atoms of stress[a][t][3+c]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void momentum_flux_kernel(
+    const T *__restrict__ stress, int64_t n_atoms, int64_t n_frames,
+    int64_t atoms_per_chunk, double *__restrict__ partial) {
+  const int64_t col = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t n_cols = n_frames * 3;
+  if (col >= n_cols) return;
+  const int64_t t = col / 3;
+  const int c = static_cast<int>(col - t * 3);
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  const int64_t row_len = n_frames * 6;
+  const T *p = stress + a0 * row_len + t * 6 + 3 + c;
+  double acc = 0.0;
+  int64_t a = a0;
+  for (; a + kUnroll <= a1; a += kUnroll) {
+    double vals[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) vals[u] = static_cast<double>(p[u * row_len]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) acc = acc + vals[u];
+    p += kUnroll * row_len;
+  }
+  for (; a < a1; ++a) {
+    acc = acc + static_cast<double>(*p);
+    p += row_len;
+  }
+  partial[static_cast<int64_t>(blockIdx.y) * n_cols + col] = acc;
+}
+
+// partial[chunk][0][t*3+c] = sum_a (ke+pe) * v_c ; partial[chunk][1][t*3+c] = sum_a phi_c
+// with phi = S . v for the symmetric stress stored as xx,yy,zz,xy,xz,yz.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void thermal_flux_kernel(
+    const T *__restrict__ stress, const T *__restrict__ vel, const T *__restrict__ ke,
+    const T *__restrict__ pe, int64_t n_atoms, int64_t n_frames, int64_t atoms_per_chunk,
+    double *__restrict__ partial) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (t >= n_frames) return;
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  double ev[3] = {0.0, 0.0, 0.0};
+  double ph[3] = {0.0, 0.0, 0.0};
+  for (int64_t a = a0; a < a1; ++a) {
+    const int64_t at = a * n_frames + t;
+    double s[6], v[3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s[i] = static_cast<double>(stress[at * 6 + i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = static_cast<double>(vel[at * 3 + i]);
+    const double e = static_cast<double>(ke[at]) + static_cast<double>(pe[at]);
+    ph[0] = ph[0] + ((s[0] * v[0] + s[3] * v[1]) + s[4] * v[2]);
+    ph[1] = ph[1] + ((s[3] * v[0] + s[1] * v[1]) + s[5] * v[2]);
+    ph[2] = ph[2] + ((s[4] * v[0] + s[5] * v[1]) + s[2] * v[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ev[i] = ev[i] + e * v[i];
+  }
+  const int64_t n_cols = n_frames * 3;
+  double *dst = partial + static_cast<int64_t>(blockIdx.y) * 2 * n_cols;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dst[t * 3 + i] = ev[i];
+    dst[n_cols + t * 3 + i] = ph[i];
+  }
+}
+
+// out[col] (+)= sum over chunks, in chunk order.  planes == 2 combines the two
+// partial sums of the thermal flux as (sum of plane 0) - (sum of plane 1).
+__global__ __launch_bounds__(kThreads) void combine_chunks_kernel(
+    const double *__restrict__ partial, int n_chunks, int planes, int64_t n_cols,
+    double *__restrict__ out, int accumulate) {
+  const int64_t col = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (col >= n_cols) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const double *p = partial + static_cast<int64_t>(c) * planes * n_cols;
+    s0 = s0 + p[col];
+    if (planes == 2) s1 = s1 + p[n_cols + col];
+  }
+  const double r = (planes == 2) ? (s0 - s1) : s0;
+  out[col] = accumulate ? (out[col] + r) : r;
+}
+
+struct ChunkPlan {
+  int64_t col_blocks;
+  int64_t n_chunks;
+  int64_t atoms_per_chunk;
+};
+
+ChunkPlan plan_chunks(int64_t n_atoms, int64_t threads_needed) {
+  ChunkPlan p;
+  p.col_blocks = ceil_div(threads_needed, kThreads);
+  int64_t want = ceil_div(4096, p.col_blocks);          // aim for >= 4096 blocks
+  int64_t max_chunks = ceil_div(n_atoms, 4 * kUnroll);  // at least 32 atoms per chunk
+  if (max_chunks < 1) max_chunks = 1;
+  p.n_chunks = want < max_chunks ? want : max_chunks;
+  if (p.n_chunks < 1) p.n_chunks = 1;
+  if (p.n_chunks > 65535) p.n_chunks = 65535;
+  p.atoms_per_chunk = ceil_div(n_atoms, p.n_chunks);
+  if (p.atoms_per_chunk < 1) p.atoms_per_chunk = 1;
+  p.n_chunks = ceil_div(n_atoms, p.atoms_per_chunk);
+  if (p.n_chunks < 1) p.n_chunks = 1;
+  return p;
+}
+
+// Writes the combined result to `out` (device or host).
+int finish(const DeviceBuffer &partial, int n_chunks, int planes, int64_t n_cols,
+           double *out, int out_location, int accumulate, hipStream_t stream) {
+  const unsigned blocks = static_cast<unsigned>(ceil_div(n_cols, kThreads));
+  if (out_location == MDX_DEVICE) {
+    hipLaunchKernelGGL(combine_chunks_kernel, dim3(blocks), dim3(kThreads), 0, stream,
+                       partial.as<double>(), n_chunks, planes, n_cols, out, accumulate);
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
+  }
+  DeviceBuffer result;
+  MDX_TRY(result.alloc(sizeof(double) * static_cast<size_t>(n_cols)));
+  hipLaunchKernelGGL(combine_chunks_kernel, dim3(blocks), dim3(kThreads), 0, stream,
+                     partial.as<double>(), n_chunks, planes, n_cols, result.as<double>(), 0);
+  MDX_HIP(hipGetLastError());
+  std::vector<double> host(static_cast<size_t>(n_cols));
+  MDX_HIP(hipMemcpyAsync(host.data(), result.ptr, sizeof(double) * host.size(),
+                         hipMemcpyDeviceToHost, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  for (int64_t i = 0; i < n_cols; ++i) out[i] = accumulate ? out[i] + host[i] : host[i];
+  return MDX_OK;
+}
+
+int check_common(const void *x, int dtype, int location, int64_t n_atoms, int64_t n_frames,
+                 const double *out, int out_location) {
+  MDX_REQUIRE(x != nullptr && out != nullptr, "null argument");
+  MDX_REQUIRE(dtype == MDX_F32 || dtype == MDX_F64, "dtype must be MDX_F32 or MDX_F64");
+  MDX_REQUIRE(location == MDX_HOST || location == MDX_DEVICE, "bad location");
+  MDX_REQUIRE(out_location == MDX_HOST || out_location == MDX_DEVICE, "bad out_location");
+  MDX_REQUIRE(n_atoms >= 0 && n_frames >= 0, "negative size");
+  return MDX_OK;
+}
+
+int zero_result(double *out, int out_location, int64_t n_cols, int accumulate,
+                hipStream_t stream) {
+  if (accumulate || n_cols == 0) return MDX_OK;
+  if (out_location == MDX_HOST) {
+    memset(out, 0, sizeof(double) * static_cast<size_t>(n_cols));
+  } else {
+    MDX_HIP(hipMemsetAsync(out, 0, sizeof(double) * static_cast<size_t>(n_cols), stream));
+  }
+  return MDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_atoms,
+                          int64_t n_frames, int k, const double *weights,
+                          double scalar_weight, double *out, int out_location,
+                          int accumulate) {
+  MDX_TRY(check_common(x, dtype, x_location, n_atoms, n_frames, out, out_location));
+  MDX_REQUIRE(k >= 1 && k <= 64, "k out of range");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  const int64_t row_len = n_frames * k;
+  if (n_atoms == 0 || row_len == 0) return zero_result(out, out_location, row_len, accumulate, stream);
+
+  DeviceBuffer x_staged, w_dev, partial;
+  const void *dx = nullptr;
+  MDX_TRY(to_device(x, x_location, static_cast<size_t>(n_atoms) * row_len * dtype_size(dtype),
+                    x_staged, stream, &dx));
+  const double *dw = nullptr;
+  if (weights != nullptr) {
+    MDX_TRY(w_dev.alloc(sizeof(double) * static_cast<size_t>(n_atoms)));
+    MDX_HIP(hipMemcpyAsync(w_dev.ptr, weights, sizeof(double) * n_atoms,
+                           hipMemcpyHostToDevice, stream));
+    dw = w_dev.as<double>();
+  }
+  const int vec = (dtype == MDX_F32) ? 4 : 2;
+  const bool aligned = (row_len % vec == 0) && (reinterpret_cast<uintptr_t>(dx) % 16 == 0);
+  const int64_t threads_needed = aligned ? row_len / vec : row_len;
+  const ChunkPlan plan = plan_chunks(n_atoms, threads_needed);
+  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * row_len));
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  if (dtype == MDX_F32) {
+    const float *xf = static_cast<const float *>(dx);
+    if (aligned)
+      hipLaunchKernelGGL((weighted_sum_kernel<float, 4>), grid, dim3(kThreads), 0, stream, xf,
+                         dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial.as<double>());
+    else
+      hipLaunchKernelGGL((weighted_sum_kernel<float, 1>), grid, dim3(kThreads), 0, stream, xf,
+                         dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial.as<double>());
+  } else {
+    const double *xd = static_cast<const double *>(dx);
+    if (aligned)
+      hipLaunchKernelGGL((weighted_sum_kernel<double, 2>), grid, dim3(kThreads), 0, stream,
+                         xd, dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial.as<double>());
+    else
+      hipLaunchKernelGGL((weighted_sum_kernel<double, 1>), grid, dim3(kThreads), 0, stream,
+                         xd, dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial.as<double>());
+  }
+  MDX_HIP(hipGetLastError());
+  MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, row_len, out, out_location,
+                 accumulate, stream));
+  // scoped device buffers are released on return
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+int mdx_momentum_flux(const void *stress, int dtype, int location, int64_t n_atoms,
+                      int64_t n_frames, double *out, int out_location, int accumulate) {
+  MDX_TRY(check_common(stress, dtype, location, n_atoms, n_frames, out, out_location));
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  const int64_t n_cols = n_frames * 3;
+  if (n_atoms == 0 || n_cols == 0) return zero_result(out, out_location, n_cols, accumulate, stream);
+  DeviceBuffer staged, partial;
+  const void *ds = nullptr;
+  MDX_TRY(to_device(stress, location,
+                    static_cast<size_t>(n_atoms) * n_frames * 6 * dtype_size(dtype), staged,
+                    stream, &ds));
+  const ChunkPlan plan = plan_chunks(n_atoms, n_cols);
+  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  if (dtype == MDX_F32)
+    hipLaunchKernelGGL(momentum_flux_kernel<float>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const float *>(ds), n_atoms, n_frames,
+                       plan.atoms_per_chunk, partial.as<double>());
+  else
+    hipLaunchKernelGGL(momentum_flux_kernel<double>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const double *>(ds), n_atoms, n_frames,
+                       plan.atoms_per_chunk, partial.as<double>());
+  MDX_HIP(hipGetLastError());
+  MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,
+                 accumulate, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+int mdx_thermal_flux(const void *stress, const void *vel, const void *ke, const void *pe,
+                     int dtype, int location, int64_t n_atoms, int64_t n_frames,
+                     double *out, int out_location, int accumulate) {
+  MDX_TRY(check_common(stress, dtype, location, n_atoms, n_frames, out, out_location));
+  MDX_REQUIRE(vel != nullptr && ke != nullptr && pe != nullptr, "null argument");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  const int64_t n_cols = n_frames * 3;
+  if (n_atoms == 0 || n_cols == 0) return zero_result(out, out_location, n_cols, accumulate, stream);
+  DeviceBuffer st_s, st_v, st_k, st_p, partial;
+  const void *ds = nullptr, *dv = nullptr, *dk = nullptr, *dp = nullptr;
+  const size_t unit = static_cast<size_t>(n_atoms) * n_frames * dtype_size(dtype);
+  MDX_TRY(to_device(stress, location, unit * 6, st_s, stream, &ds));
+  MDX_TRY(to_device(vel, location, unit * 3, st_v, stream, &dv));
+  MDX_TRY(to_device(ke, location, unit, st_k, stream, &dk));
+  MDX_TRY(to_device(pe, location, unit, st_p, stream, &dp));
+  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
+  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * 2 * n_cols));
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  if (dtype == MDX_F32)
+    hipLaunchKernelGGL(thermal_flux_kernel<float>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const float *>(ds), static_cast<const float *>(dv),
+                       static_cast<const float *>(dk), static_cast<const float *>(dp),
+                       n_atoms, n_frames, plan.atoms_per_chunk, partial.as<double>());
+  else
+    hipLaunchKernelGGL(thermal_flux_kernel<double>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const double *>(ds), static_cast<const double *>(dv),
+                       static_cast<const double *>(dk), static_cast<const double *>(dp),
+                       n_atoms, n_frames, plan.atoms_per_chunk, partial.as<double>());
+  MDX_HIP(hipGetLastError());
+  MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 2, n_cols, out, out_location,
+                 accumulate, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+}  // extern "C"

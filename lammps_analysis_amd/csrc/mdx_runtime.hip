@@ -1,0 +1,207 @@
+// Runtime part of libmdx: error text, device selection, the per-device library
+// stream, raw device memory and event timing.
+#include "mdx_common.h"
+
+namespace mdx {
+
+static thread_local char g_error[1024] = {0};
+
+char *error_buffer() { return g_error; }
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static constexpr int kMaxDevices = 64;
+static hipStream_t g_streams[kMaxDevices] = {nullptr};
+
+int get_stream(hipStream_t *stream) {
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices)
+    return fail(MDX_ERR_DEVICE, "device index %d out of range", dev);
+  if (g_streams[dev] == nullptr) {
+    MDX_HIP(hipStreamCreateWithFlags(&g_streams[dev], hipStreamNonBlocking));
+  }
+  *stream = g_streams[dev];
+  return MDX_OK;
+}
+
+int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
+              hipStream_t stream, const void **dptr) {
+  if (src == nullptr) return fail(MDX_ERR_INVALID_ARGUMENT, "null data pointer");
+  if (location == MDX_DEVICE) {
+    *dptr = src;
+    return MDX_OK;
+  }
+  if (location != MDX_HOST)
+    return fail(MDX_ERR_INVALID_ARGUMENT, "location must be MDX_HOST or MDX_DEVICE");
+  MDX_TRY(staging.alloc(bytes));
+  MDX_HIP(hipMemcpyAsync(staging.ptr, src, bytes, hipMemcpyHostToDevice, stream));
+  *dptr = staging.ptr;
+  return MDX_OK;
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+struct mdx_event_s {
+  hipEvent_t ev;
+};
+
+extern "C" {
+
+int mdx_version(void) { return 100; }
+
+const char *mdx_last_error(void) { return error_buffer(); }
+
+int mdx_device_count(int *count) {
+  MDX_REQUIRE(count != nullptr, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(MDX_ERR_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return MDX_OK;
+}
+
+int mdx_set_device(int device) {
+  MDX_HIP(hipSetDevice(device));
+  return MDX_OK;
+}
+
+int mdx_device_info(char *name, size_t name_len, int *compute_units,
+                    uint64_t *memory_bytes) {
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  MDX_HIP(hipGetDeviceProperties(&prop, dev));
+  if (name != nullptr && name_len > 0) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (memory_bytes) *memory_bytes = static_cast<uint64_t>(prop.totalGlobalMem);
+  return MDX_OK;
+}
+
+int mdx_synchronize(void) {
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  MDX_HIP(hipStreamSynchronize(s));
+  return MDX_OK;
+}
+
+int mdx_malloc(void **dptr, size_t bytes) {
+  MDX_REQUIRE(dptr != nullptr, "dptr is null");
+  *dptr = nullptr;
+  MDX_HIP(hipMalloc(dptr, bytes == 0 ? 16 : bytes));
+  return MDX_OK;
+}
+
+int mdx_free(void *dptr) {
+  if (dptr == nullptr) return MDX_OK;
+  MDX_HIP(hipFree(dptr));
+  return MDX_OK;
+}
+
+int mdx_memcpy_h2d(void *dptr, const void *host, size_t bytes) {
+  MDX_REQUIRE(dptr != nullptr && host != nullptr, "null pointer");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  MDX_HIP(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, s));
+  MDX_HIP(hipStreamSynchronize(s));
+  return MDX_OK;
+}
+
+int mdx_memcpy_d2h(void *host, const void *dptr, size_t bytes) {
+  MDX_REQUIRE(dptr != nullptr && host != nullptr, "null pointer");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  MDX_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, s));
+  MDX_HIP(hipStreamSynchronize(s));
+  return MDX_OK;
+}
+
+int mdx_memset(void *dptr, int byte_value, size_t bytes) {
+  MDX_REQUIRE(dptr != nullptr, "null pointer");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  MDX_HIP(hipMemsetAsync(dptr, byte_value, bytes, s));
+  return MDX_OK;
+}
+
+int mdx_event_create(mdx_event_t *ev) {
+  MDX_REQUIRE(ev != nullptr, "ev is null");
+  mdx_event_s *e = new (std::nothrow) mdx_event_s;
+  if (!e) return fail(MDX_ERR_OUT_OF_MEMORY, "out of host memory");
+  hipError_t rc = hipEventCreate(&e->ev);
+  if (rc != hipSuccess) {
+    delete e;
+    return fail(MDX_ERR_DEVICE, "hipEventCreate failed: %s", hipGetErrorString(rc));
+  }
+  *ev = e;
+  return MDX_OK;
+}
+
+int mdx_event_record(mdx_event_t ev) {
+  MDX_REQUIRE(ev != nullptr, "ev is null");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  MDX_HIP(hipEventRecord(ev->ev, s));
+  return MDX_OK;
+}
+
+int mdx_event_elapsed_ms(mdx_event_t start, mdx_event_t stop, float *ms) {
+  MDX_REQUIRE(start && stop && ms, "null argument");
+  MDX_HIP(hipEventSynchronize(stop->ev));
+  MDX_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return MDX_OK;
+}
+
+int mdx_event_destroy(mdx_event_t ev) {
+  if (!ev) return MDX_OK;
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return MDX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------- synthetic fill (bench)
+
+// 64-bit mix (splitmix64 finaliser) -> 24 random bits -> float in [0,1).
+__device__ __forceinline__ float mdx_hash_unit(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void mdx_fill_uniform_kernel(float *out, uint64_t n, uint64_t seed,
+                                        float lo, float hi) {
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (; i < n; i += stride) out[i] = lo + (hi - lo) * mdx_hash_unit(seed, i);
+}
+
+extern "C" int mdx_fill_uniform_f32(float *dptr, uint64_t n, uint64_t seed, float lo,
+                                    float hi) {
+  MDX_REQUIRE(dptr != nullptr, "null pointer");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  if (n == 0) return MDX_OK;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mdx_fill_uniform_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(256), 0, s, dptr, n, seed, lo, hi);
+  MDX_HIP(hipGetLastError());
+  return MDX_OK;
+}

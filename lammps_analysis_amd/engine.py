@@ -1,0 +1,377 @@
+"""NumPy-facing wrappers around the libmdx C-ABI.
+
+These functions are the only place where the calculators touch the GPU.  Inputs
+are NumPy arrays (host memory, staged by the library) or :class:`DeviceArray`
+objects (data already resident in HBM); outputs are NumPy arrays.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import (MDX_DEVICE, MDX_F32, MDX_F64, MDX_HOST, MDX_RDF_LITERAL_KERNEL,
+                   MDX_RDF_STRICT_REFERENCE_MASKS, check)
+
+ArrayLike = Union[np.ndarray, "DeviceArray"]
+
+
+def set_device(index: int) -> None:
+    check(_lib.load().mdx_set_device(int(index)))
+
+
+def synchronize() -> None:
+    check(_lib.load().mdx_synchronize())
+
+
+def device_info() -> dict:
+    name = ctypes.create_string_buffer(256)
+    cus = ctypes.c_int(0)
+    mem = ctypes.c_uint64(0)
+    check(_lib.load().mdx_device_info(name, 256, ctypes.byref(cus), ctypes.byref(mem)))
+    return {"name": name.value.decode(), "compute_units": cus.value,
+            "memory_bytes": mem.value}
+
+
+def _dtype_code(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return MDX_F32
+    if dtype == np.float64:
+        return MDX_F64
+    raise TypeError(f"unsupported dtype {dtype}; use float32 or float64")
+
+
+class DeviceArray:
+    """A C-contiguous array living in device memory (allocated by libmdx)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        ptr = ctypes.c_void_p()
+        check(_lib.load().mdx_malloc(ctypes.byref(ptr), self.nbytes))
+        self.ptr = ptr.value
+
+    @classmethod
+    def from_numpy(cls, array: np.ndarray) -> "DeviceArray":
+        array = np.ascontiguousarray(array)
+        out = cls(array.shape, array.dtype)
+        if out.nbytes:
+            check(_lib.load().mdx_memcpy_h2d(out.ptr, array.ctypes.data, out.nbytes))
+        return out
+
+    def to_numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(_lib.load().mdx_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def fill_uniform(self, seed: int, lo: float, hi: float) -> None:
+        """Deterministic synthetic fill (float32 only); see mdx_fill_uniform_f32."""
+        if self.dtype != np.float32:
+            raise TypeError("fill_uniform needs a float32 array")
+        n = self.nbytes // 4
+        check(_lib.load().mdx_fill_uniform_f32(self.ptr, n, int(seed), float(lo), float(hi)))
+
+    def free(self) -> None:
+        if getattr(self, "ptr", None):
+            _lib.load().mdx_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def uniform_fill_reference(n: int, seed: int, lo: float, hi: float, start: int = 0) -> np.ndarray:
+    """NumPy restatement of ``mdx_fill_uniform_f32`` for elements start..start+n-1."""
+    i = np.arange(start, start + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (i + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    lo32 = np.float32(lo)
+    span = np.float32(np.float32(hi) - lo32)
+    return (lo32 + (span * u).astype(np.float32)).astype(np.float32)
+
+
+def _as_input(x: ArrayLike):
+    """(pointer, dtype code, location, shape, keepalive) of an input array."""
+    if isinstance(x, DeviceArray):
+        return x.ptr, _dtype_code(x.dtype), MDX_DEVICE, x.shape, x
+    arr = np.asarray(x)
+    if arr.dtype not in (np.float32, np.float64):
+        arr = arr.astype(np.float64)
+    arr = np.ascontiguousarray(arr)
+    return arr.ctypes.data, _dtype_code(arr.dtype), MDX_HOST, arr.shape, arr
+
+
+class Event:
+    """HIP event on the library stream."""
+
+    def __init__(self):
+        ptr = ctypes.c_void_p()
+        check(_lib.load().mdx_event_create(ctypes.byref(ptr)))
+        self.ptr = ptr.value
+
+    def record(self) -> None:
+        check(_lib.load().mdx_event_record(self.ptr))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = ctypes.c_float(0.0)
+        check(_lib.load().mdx_event_elapsed_ms(self.ptr, stop.ptr, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                _lib.load().mdx_event_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------- RDF
+
+
+class RdfEngine:
+    """Pair-distance histograms for one set of species on the current device."""
+
+    def __init__(self, n_per_species: Sequence[int], box, cutoff, nbins: int,
+                 strict_reference_masks: bool = True, literal_kernel: bool = False):
+        self.n_per_species = [int(n) for n in n_per_species]
+        self.n_species = len(self.n_per_species)
+        self.n_keys = self.n_species * (self.n_species + 1) // 2
+        self.nbins = int(nbins)
+        flags = 0
+        if strict_reference_masks:
+            flags |= MDX_RDF_STRICT_REFERENCE_MASKS
+        if literal_kernel:
+            flags |= MDX_RDF_LITERAL_KERNEL
+        nps = (ctypes.c_int64 * self.n_species)(*self.n_per_species)
+        box32 = np.asarray(box, dtype=np.float32)
+        if box32.shape != (3,):
+            raise ValueError("box must have three entries")
+        boxc = (ctypes.c_float * 3)(*[float(b) for b in box32])
+        handle = ctypes.c_void_p()
+        check(_lib.load().mdx_rdf_create(ctypes.byref(handle), self.n_species, nps, boxc,
+                                         ctypes.c_float(float(np.float32(cutoff))),
+                                         self.nbins, flags))
+        self._handle = handle.value
+
+    @property
+    def num_tiles(self) -> int:
+        n = ctypes.c_int64(0)
+        check(_lib.load().mdx_rdf_num_tiles(self._handle, ctypes.byref(n)))
+        return int(n.value)
+
+    def accumulate(self, species_positions: Sequence[ArrayLike], frames=None,
+                   shard_rank: int = 0, shard_count: int = 1) -> None:
+        """Add the histogram of the selected frames.
+
+        ``species_positions[s]`` is ``[n_s, F, 3]`` (all on the host or all on the
+        device, one dtype); ``frames`` indexes axis 1 (default: every frame).
+        """
+        if len(species_positions) != self.n_species:
+            raise ValueError("one position array per species is required")
+        infos = [_as_input(p) for p in species_positions]
+        locations = {i[2] for i in infos}
+        dtypes = {i[1] for i in infos}
+        if len(locations) != 1 or len(dtypes) != 1:
+            raise ValueError("all species arrays must share location and dtype")
+        strides = set()
+        for info, n in zip(infos, self.n_per_species):
+            shape = info[3]
+            if len(shape) != 3 or shape[2] != 3 or shape[0] != n:
+                raise ValueError(f"expected shape ({n}, F, 3), got {shape}")
+            strides.add(shape[1])
+        if len(strides) != 1:
+            raise ValueError("all species arrays must hold the same number of frames")
+        frame_stride = strides.pop()
+        ptrs = (ctypes.c_void_p * self.n_species)(*[i[0] for i in infos])
+        if frames is None:
+            frames_ptr = None
+            n_frames = frame_stride
+        else:
+            frames_arr = np.ascontiguousarray(frames, dtype=np.int64)
+            frames_ptr = frames_arr.ctypes.data_as(_lib.c_i64_p)
+            n_frames = len(frames_arr)
+        check(_lib.load().mdx_rdf_accumulate(
+            self._handle, ptrs, dtypes.pop(), locations.pop(), frame_stride, frames_ptr,
+            n_frames, int(shard_rank), int(shard_count)))
+
+    def read(self) -> np.ndarray:
+        hist = np.zeros((self.n_keys, self.nbins), dtype=np.uint64)
+        check(_lib.load().mdx_rdf_read(self._handle, hist.ctypes.data_as(_lib.c_u64_p)))
+        return hist
+
+    def reset(self) -> None:
+        check(_lib.load().mdx_rdf_reset(self._handle))
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _lib.load().mdx_rdf_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- reductions
+
+
+def _out_buffer(out: Optional[np.ndarray], shape, accumulate: bool) -> np.ndarray:
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an `out` array")
+        return np.zeros(shape, dtype=np.float64)
+    if out.dtype != np.float64 or not out.flags.c_contiguous or out.shape != tuple(shape):
+        raise ValueError(f"out must be a C-contiguous float64 array of shape {shape}")
+    return out
+
+
+def weighted_atom_sum(x: ArrayLike, scalar_weight: float = 1.0,
+                      weights: Optional[np.ndarray] = None, out: Optional[np.ndarray] = None,
+                      accumulate: bool = False) -> np.ndarray:
+    """``out[t, c] (+)= sum_a w_a * x[a, t, c]`` in float64; x is ``[N, T, k]``."""
+    ptr, dt, loc, shape, keep = _as_input(x)
+    if len(shape) != 3:
+        raise ValueError("x must have shape (n_atoms, n_frames, k)")
+    n_atoms, n_frames, k = shape
+    out = _out_buffer(out, (n_frames, k), accumulate)
+    wptr = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if len(w) != n_atoms:
+            raise ValueError("weights must have one entry per atom")
+        wptr = w.ctypes.data_as(_lib.c_f64_p)
+    check(_lib.load().mdx_weighted_atom_sum(ptr, dt, loc, n_atoms, n_frames, k, wptr,
+                                            float(scalar_weight), out.ctypes.data, MDX_HOST,
+                                            1 if accumulate else 0))
+    return out
+
+
+def momentum_flux(stress: ArrayLike, out: Optional[np.ndarray] = None,
+                  accumulate: bool = False) -> np.ndarray:
+    ptr, dt, loc, shape, keep = _as_input(stress)
+    if len(shape) != 3 or shape[2] != 6:
+        raise ValueError("stress must have shape (n_atoms, n_frames, 6)")
+    out = _out_buffer(out, (shape[1], 3), accumulate)
+    check(_lib.load().mdx_momentum_flux(ptr, dt, loc, shape[0], shape[1], out.ctypes.data,
+                                        MDX_HOST, 1 if accumulate else 0))
+    return out
+
+
+def thermal_flux(stress: ArrayLike, vel: ArrayLike, ke: ArrayLike, pe: ArrayLike,
+                 out: Optional[np.ndarray] = None, accumulate: bool = False) -> np.ndarray:
+    infos = [_as_input(a) for a in (stress, vel, ke, pe)]
+    if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
+        raise ValueError("all thermal-flux inputs must share dtype and location")
+    n_atoms, n_frames = infos[0][3][0], infos[0][3][1]
+    expect = [(n_atoms, n_frames, 6), (n_atoms, n_frames, 3), (n_atoms, n_frames, 1),
+              (n_atoms, n_frames, 1)]
+    for info, shp in zip(infos, expect):
+        if tuple(info[3]) != shp:
+            raise ValueError(f"expected shape {shp}, got {info[3]}")
+    out = _out_buffer(out, (n_frames, 3), accumulate)
+    check(_lib.load().mdx_thermal_flux(infos[0][0], infos[1][0], infos[2][0], infos[3][0],
+                                       infos[0][1], infos[0][2], n_atoms, n_frames,
+                                       out.ctypes.data, MDX_HOST, 1 if accumulate else 0))
+    return out
+
+
+# -------------------------------------------------------------- correlations
+
+
+@dataclasses.dataclass
+class Moments:
+    """Streaming mean / sum of squared deviations over ``n`` windows."""
+
+    n: int
+    mean: np.ndarray
+    m2: np.ndarray
+
+    def merge(self, other: "Moments") -> "Moments":
+        """Parallel-variance (Chan et al.) combination of two window sets."""
+        if other.n == 0:
+            return self
+        if self.n == 0:
+            return other
+        n = self.n + other.n
+        delta = other.mean - self.mean
+        mean = self.mean + delta * (other.n / n)
+        m2 = self.m2 + other.m2 + delta * delta * (self.n * other.n / n)
+        return Moments(n, mean, m2)
+
+    def std(self) -> np.ndarray:
+        """Population standard deviation, ``np.std(..., axis=0)`` of the windows."""
+        return np.sqrt(self.m2 / self.n)
+
+
+def _tau_array(tau) -> np.ndarray:
+    tau = np.ascontiguousarray(tau, dtype=np.int32)
+    if tau.ndim != 1 or len(tau) == 0:
+        raise ValueError("tau must be a non-empty 1-D index array")
+    return tau
+
+
+def acf_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: int, tau,
+                scale: float = 1.0, integral_scale: float = 1.0,
+                time: Optional[np.ndarray] = None):
+    """Windowed autocorrelation of ``x`` ``[S, T, k]``; see ``mdx_acf_windows``.
+
+    Returns ``(acf_sum, moments)``; ``moments`` is ``None`` without ``time``.
+    """
+    ptr, dt, loc, shape, keep = _as_input(x)
+    if len(shape) != 3:
+        raise ValueError("x must have shape (n_series, n_frames, k)")
+    tau = _tau_array(tau)
+    R = len(tau)
+    acf = np.zeros(R, dtype=np.float64)
+    n_win = ctypes.c_int64(0)
+    if time is not None:
+        time_arr = np.ascontiguousarray(time, dtype=np.float64)
+        if time_arr.shape != (R,):
+            raise ValueError("time must have one entry per tau value")
+        mean = np.zeros(max(R - 1, 1), dtype=np.float64)
+        m2 = np.zeros(max(R - 1, 1), dtype=np.float64)
+        tptr = time_arr.ctypes.data_as(_lib.c_f64_p)
+        mptr = mean.ctypes.data_as(_lib.c_f64_p)
+        m2ptr = m2.ctypes.data_as(_lib.c_f64_p)
+    else:
+        tptr = mptr = m2ptr = None
+    check(_lib.load().mdx_acf_windows(
+        ptr, dt, loc, shape[0], shape[1], shape[2], int(correlation_time), int(win_begin),
+        int(win_end), tau.ctypes.data_as(_lib.c_i32_p), R, float(scale),
+        float(integral_scale), tptr, acf.ctypes.data_as(_lib.c_f64_p), mptr, m2ptr,
+        ctypes.byref(n_win)))
+    moments = None
+    if time is not None:
+        moments = Moments(int(n_win.value), mean[:R - 1], m2[:R - 1])
+    return acf, moments
+
+
+def msd_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: int, tau,
+                scale: float = 1.0) -> np.ndarray:
+    """Windowed squared displacement sums of ``x`` ``[S, T, k]``; see ``mdx_msd_windows``."""
+    ptr, dt, loc, shape, keep = _as_input(x)
+    if len(shape) != 3:
+        raise ValueError("x must have shape (n_series, n_frames, k)")
+    tau = _tau_array(tau)
+    msd = np.zeros(len(tau), dtype=np.float64)
+    check(_lib.load().mdx_msd_windows(
+        ptr, dt, loc, shape[0], shape[1], shape[2], int(correlation_time), int(win_begin),
+        int(win_end), tau.ctypes.data_as(_lib.c_i32_p), len(tau), float(scale),
+        msd.ctypes.data_as(_lib.c_f64_p)))
+    return msd
