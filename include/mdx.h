@@ -77,6 +77,21 @@ int mdx_event_record(mdx_event_t ev);
 int mdx_event_elapsed_ms(mdx_event_t start, mdx_event_t stop, float *ms);
 int mdx_event_destroy(mdx_event_t ev);
 
+/* Kernel timing.  While profiling is on, every kernel launch of the slots below
+ * is bracketed by HIP events on the library stream; mdx_profile_query waits for
+ * the stream and returns the summed kernel time and launch count of one slot
+ * since the last mdx_profile_reset. */
+#define MDX_SLOT_RDF_PACK 0
+#define MDX_SLOT_RDF_TILE 1
+#define MDX_SLOT_ATOM_SUM 2
+#define MDX_SLOT_ACF_PARTIAL 3
+#define MDX_SLOT_ACF_FINISH 4
+#define MDX_SLOT_MSD 5
+#define MDX_NUM_SLOTS 6
+int mdx_profile_enable(int on);
+int mdx_profile_reset(void);
+int mdx_profile_query(int slot, double *total_ms, int64_t *launches);
+
 /* Fill a device array with a deterministic synthetic trajectory (bench only):
  * element i gets lo + (hi-lo)*u(seed, i), u = 24-bit counter hash in [0,1). */
 int mdx_fill_uniform_f32(float *dptr, uint64_t n, uint64_t seed, float lo, float hi);

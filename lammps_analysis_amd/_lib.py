@@ -60,6 +60,9 @@ SIGNATURES = {
     "mdx_event_record": (ctypes.c_int, [ctypes.c_void_p]),
     "mdx_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32_p]),
     "mdx_event_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mdx_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "mdx_profile_reset": (ctypes.c_int, []),
+    "mdx_profile_query": (ctypes.c_int, [ctypes.c_int, c_f64_p, c_i64_p]),
     "mdx_fill_uniform_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_uint64, ctypes.c_float,
                                             ctypes.c_float]),

@@ -84,6 +84,21 @@ struct DeviceBuffer {
 int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
               hipStream_t stream, const void **dptr);
 
+// Brackets the kernel launches issued during its lifetime with HIP events when
+// profiling is enabled (mdx_profile_enable); free otherwise.
+struct KernelTimer {
+  KernelTimer(int slot, hipStream_t stream);
+  ~KernelTimer();
+  KernelTimer(const KernelTimer &) = delete;
+  KernelTimer &operator=(const KernelTimer &) = delete;
+
+ private:
+  int slot_;
+  hipStream_t stream_;
+  hipEvent_t start_ = nullptr;
+  hipEvent_t stop_ = nullptr;
+};
+
 inline size_t dtype_size(int dtype) { return dtype == MDX_F64 ? 8 : 4; }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

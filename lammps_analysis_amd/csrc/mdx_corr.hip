@@ -363,10 +363,13 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
                        correlation_time, win_begin, n_win, wpb, d_tau.as<int32_t>(), R,   \
                        ti.D, ti.identity ? 1 : 0, series_per_chunk, d_C.as<double>());    \
   } while (0)
-  if (dtype == MDX_F32) {
-    if (k == 3) MDX_LAUNCH_ACF(float, 3); else MDX_LAUNCH_ACF(float, 0);
-  } else {
-    if (k == 3) MDX_LAUNCH_ACF(double, 3); else MDX_LAUNCH_ACF(double, 0);
+  {
+    KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
+    if (dtype == MDX_F32) {
+      if (k == 3) MDX_LAUNCH_ACF(float, 3); else MDX_LAUNCH_ACF(float, 0);
+    } else {
+      if (k == 3) MDX_LAUNCH_ACF(double, 3); else MDX_LAUNCH_ACF(double, 0);
+    }
   }
 #undef MDX_LAUNCH_ACF
   MDX_HIP(hipGetLastError());
@@ -383,11 +386,14 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
   MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_finish_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(lds_b)));
-  hipLaunchKernelGGL(acf_finish_kernel, dim3(static_cast<unsigned>(n_blocks_b)),
-                     dim3(kThreads), lds_b, stream, d_C.as<double>(),
-                     static_cast<int>(n_chunks), n_win, wins_per_block_b, R, scale,
-                     integral_scale, want_integral ? d_time.as<double>() : nullptr,
-                     d_acf.as<double>(), d_mean.as<double>(), d_m2.as<double>());
+  {
+    KernelTimer timer(MDX_SLOT_ACF_FINISH, stream);
+    hipLaunchKernelGGL(acf_finish_kernel, dim3(static_cast<unsigned>(n_blocks_b)),
+                       dim3(kThreads), lds_b, stream, d_C.as<double>(),
+                       static_cast<int>(n_chunks), n_win, wins_per_block_b, R, scale,
+                       integral_scale, want_integral ? d_time.as<double>() : nullptr,
+                       d_acf.as<double>(), d_mean.as<double>(), d_m2.as<double>());
+  }
   MDX_HIP(hipGetLastError());
 
   std::vector<double> h_acf(static_cast<size_t>(n_blocks_b) * R);
@@ -467,6 +473,7 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
   MDX_TRY(d_partial.alloc(sizeof(double) * n_blocks * R));
   MDX_TRY(d_out.alloc(sizeof(double) * R));
   dim3 grid(static_cast<unsigned>(win_blocks), static_cast<unsigned>(n_chunks));
+  KernelTimer timer(MDX_SLOT_MSD, stream);
   if (dtype == MDX_F32) {
     MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(msd_kernel<float>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,

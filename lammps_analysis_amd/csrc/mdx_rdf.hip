@@ -15,13 +15,22 @@
 //   literal : the reference's float32 operations one by one (IEEE divide, rint,
 //             separate multiply/subtract, (x*x+y*y)+z*z, IEEE sqrt, d < cutoff,
 //             float64 divide by the bin width, min, truncation);
-//   table   : the bin as a function of the float32 squared distance is monotone,
-//             so it is described exactly by one float32 threshold per bin edge,
-//             computed on the host with the literal operations.  The kernel takes
-//             an approximate bin from v_sqrt_f32 and corrects it by comparing
-//             against the two neighbouring thresholds; the minimum-image rint uses
-//             a reciprocal multiply and falls back to the IEEE divide whenever the
-//             quotient is too close to a rounding boundary to be trusted.
+//   table   : every step of the literal sequence after the coordinate difference
+//             is a monotone function of one float32 value, so it can be replaced
+//             by comparisons against float32 thresholds that the host computes
+//             with the literal operations (bisection over bit patterns):
+//               * minimum image: rint(fl(|r|/L)) >= 1 exactly when |r| >= t_wrap.
+//                 A per-frame flag (extent kernel) says whether every coordinate
+//                 difference of the frame stays below the point where the rint
+//                 would reach 2; such frames ("wrapped") use |r| - (|r| >= t_wrap
+//                 ? L : 0), whose square equals the literal one.  Other frames use
+//                 a reciprocal multiply and fall back to the IEEE divide whenever
+//                 the quotient is too close to a rounding boundary;
+//               * binning: bin(s) of the squared distance is described by one
+//                 threshold per bin edge.  The kernel takes floor(v_sqrt_f32(s) *
+//                 nbins/cutoff); only when that product lies within the error
+//                 bound of an integer does it consult the two neighbouring
+//                 thresholds (kept in LDS).
 //
 // This file must be compiled with -ffp-contract=off: a fused multiply-add in the
 // minimum-image or the squared-distance expression changes the rounding and
@@ -47,9 +56,12 @@ struct TilePair {
 struct RdfParams {
   float box[3];
   float inv_box[3];
+  float t_wrap[3];     // smallest |r| whose literal rint(r / box) is >= 1
+  float t_far[3];      // smallest |r| whose literal rint(r / box) is >= 2
   float cutoff;        // float32 cutoff (literal kernel)
   float s_cut;         // smallest float32 s with sqrtf(s) >= cutoff (table kernel)
   float inv_step;      // float32(nbins / cutoff), approximate bin scale
+  float edge_half;     // 0.5 - error bound of the approximate bin position
   double step;         // double(cutoff - 0.0f) / double(nbins)
   int nbins;
 };
@@ -140,43 +152,123 @@ __device__ __forceinline__ float exact_rint_quotient(float r, float box, float i
   return n;
 }
 
-// Table-driven equivalent of pair_literal.  thresholds[k], k = 0..nbins, is the
-// smallest float32 squared distance that falls into bin >= k (thresholds[0] = 0,
-// thresholds[nbins] = +inf); s_cut is the smallest squared distance that fails
-// d < cutoff.
-__device__ __forceinline__ void pair_table(float xi, float yi, float zi, float4 pj,
-                                           const RdfParams &p,
-                                           const float *__restrict__ thresholds,
-                                           bool allowed, uint32_t *hist) {
-  float rx = pj.x - xi;
-  float ry = pj.y - yi;
-  float rz = pj.z - zi;
-  rx = rx - exact_rint_quotient(rx, p.box[0], p.inv_box[0]) * p.box[0];
-  ry = ry - exact_rint_quotient(ry, p.box[1], p.inv_box[1]) * p.box[1];
-  rz = rz - exact_rint_quotient(rz, p.box[2], p.inv_box[2]) * p.box[2];
-  const float s = (rx * rx + ry * ry) + rz * rz;
-  if (allowed && s < p.s_cut) {
-    int b = static_cast<int>(__builtin_amdgcn_sqrtf(s) * p.inv_step);
-    b = min(b, p.nbins - 1);
-    // the estimate is off by at most one bin; the thresholds decide
-    const float lo = thresholds[b];
-    const float hi = thresholds[b + 1];
-    b += (s >= hi) ? 1 : 0;
-    b -= (s < lo) ? 1 : 0;
-    atomicAdd(&hist[b], 1u);
+// Flags the frames whose coordinate differences all stay below t_far, so that
+// the minimum-image shift is at most one box length ("wrapped" frames).
+// One block per frame; NaN padding is ignored by fminf/fmaxf.
+__global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict__ packed,
+                                                         int64_t n_pad, RdfParams p,
+                                                         int32_t *__restrict__ wrapped) {
+  __shared__ float s_min[3][4];
+  __shared__ float s_max[3][4];
+  const int f = blockIdx.x;
+  const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
+  const float inf = __builtin_inff();
+  bool ok = true;
+  for (int c = 0; c < 3; ++c) {
+    float mn = inf, mx = -inf;
+    for (int64_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+      const float v = X[c * n_pad + i];
+      mn = fminf(mn, v);
+      mx = fmaxf(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, off));
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_min[c][threadIdx.x >> 6] = mn;
+      s_max[c][threadIdx.x >> 6] = mx;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < 3; ++c) {
+      float mn = inf, mx = -inf;
+      for (int w = 0; w < 4; ++w) {
+        mn = fminf(mn, s_min[c][w]);
+        mx = fmaxf(mx, s_max[c][w]);
+      }
+      // no atom at all: mx - mn = -inf - inf = -inf < t_far
+      const float extent = mx - mn;
+      ok = ok && (extent < p.t_far[c]);
+    }
+    wrapped[f] = ok ? 1 : 0;
+  }
+}
+
+// Table-driven pair loop over one j-tile, four pairs per iteration.  Equivalent to
+// pair_literal for every input; see the file header for the argument.
+//   thr[k], k = 0..nbins: smallest float32 squared distance that falls into a bin
+//   >= k (thr[0] = 0, thr[nbins] = +inf); p.s_cut: smallest squared distance that
+//   fails d < cutoff.  Lanes without a pair to count add into a per-lane dummy slot
+//   behind the histogram, which keeps the loop free of divergent branches.
+template <bool kDiag, bool kWrapped>
+__device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
+                                                const float4 *__restrict__ tile,
+                                                uint32_t *__restrict__ hist,
+                                                const float *__restrict__ thr,
+                                                const RdfParams &p, int tid, int dummy) {
+  const int j_begin = kDiag ? (tid & ~63) : 0;
+  for (int j0 = j_begin; j0 < kTile; j0 += 4) {
+    float s[4];
+    int b[4];
+    bool keep[4], near_edge[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 pj = tile[j0 + u];
+      float ax, ay, az;
+      if (kWrapped) {
+        ax = fabsf(pj.x - xi);
+        ay = fabsf(pj.y - yi);
+        az = fabsf(pj.z - zi);
+        ax = ax - ((ax >= p.t_wrap[0]) ? p.box[0] : 0.0f);
+        ay = ay - ((ay >= p.t_wrap[1]) ? p.box[1] : 0.0f);
+        az = az - ((az >= p.t_wrap[2]) ? p.box[2] : 0.0f);
+      } else {
+        ax = pj.x - xi;
+        ay = pj.y - yi;
+        az = pj.z - zi;
+        ax = ax - exact_rint_quotient(ax, p.box[0], p.inv_box[0]) * p.box[0];
+        ay = ay - exact_rint_quotient(ay, p.box[1], p.inv_box[1]) * p.box[1];
+        az = az - exact_rint_quotient(az, p.box[2], p.inv_box[2]) * p.box[2];
+      }
+      s[u] = (ax * ax + ay * ay) + az * az;
+      keep[u] = s[u] < p.s_cut;
+      if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
+      const float t = __builtin_amdgcn_sqrtf(s[u]) * p.inv_step;
+      b[u] = static_cast<int>(t);
+      near_edge[u] = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > p.edge_half;
+    }
+    const bool fix = (keep[0] && near_edge[0]) || (keep[1] && near_edge[1]) ||
+                     (keep[2] && near_edge[2]) || (keep[3] && near_edge[3]);
+    if (__builtin_expect(fix, 0)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (keep[u] && near_edge[u]) {
+          int e = min(max(b[u], 0), p.nbins - 1);
+          const float lo = thr[e];
+          const float hi = thr[e + 1];
+          e += (s[u] >= hi) ? 1 : 0;
+          e -= (s[u] < lo) ? 1 : 0;
+          b[u] = e;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) atomicAdd(&hist[keep[u] ? b[u] : dummy], 1u);
   }
 }
 
 // ---------------------------------------------------------------- tile kernel
 
-// LDS layout: uint32 hist[nbins_pad] | float thresholds[nbins_pad + 1 (+pad)] (table
-// kernel only) | float4 tile[kTile].
+// LDS layout: uint32 hist[lds_hist_words] (bins, padding, 64 dummy slots) |
+// float thresholds[lds_thr_words] (table kernel only) | float4 tile[kTile].
 template <bool kLiteral>
 __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_group,
     const TilePair *__restrict__ pairs, RdfParams p,
-    const float *__restrict__ g_thresholds, int lds_hist_words, int lds_thr_words,
-    unsigned long long *__restrict__ g_hist) {
+    const float *__restrict__ g_thresholds, const int32_t *__restrict__ frame_wrapped,
+    int lds_hist_words, int lds_thr_words, unsigned long long *__restrict__ g_hist) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   float *thr = reinterpret_cast<float *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words));
@@ -188,16 +280,14 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
   const int f_begin = blockIdx.y * frames_per_group;
   const int f_end = min(n_frames, f_begin + frames_per_group);
 
-  for (int b = tid; b < p.nbins; b += kTile) hist[b] = 0u;
+  for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
   if (!kLiteral) {
     for (int b = tid; b <= p.nbins; b += kTile) thr[b] = g_thresholds[b];
   }
+  const int dummy = lds_hist_words - 64 + (tid & 63);
 
   const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
   const int64_t slot_j = static_cast<int64_t>(tp.tile_j) * kTile + tid;
-  // In a diagonal tile lane t only pairs with j > t: a wave can skip every j that
-  // is not above its first lane.
-  const int j_start = tp.diagonal ? ((tid & ~63) + 1) : 0;
 
   for (int f = f_begin; f < f_end; ++f) {
     const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
@@ -208,14 +298,27 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
     __syncthreads();  // previous frame's tile reads are complete (and LDS init)
     tile[tid] = mine;
     __syncthreads();
+    if (kLiteral) {
+      // In a diagonal tile lane t only pairs with j > t: a wave can skip every j
+      // that is not above its first lane.
+      const int j_start = tp.diagonal ? ((tid & ~63) + 1) : 0;
 #pragma unroll 4
-    for (int j = j_start; j < kTile; ++j) {
-      const float4 pj = tile[j];
-      const bool allowed = !tp.diagonal || (j > tid);
-      if (kLiteral) {
-        pair_literal(xi, yi, zi, pj, p, allowed, hist);
+      for (int j = j_start; j < kTile; ++j) {
+        const bool allowed = !tp.diagonal || (j > tid);
+        pair_literal(xi, yi, zi, tile[j], p, allowed, hist);
+      }
+    } else {
+      const bool wrapped = frame_wrapped[f] != 0;
+      if (tp.diagonal) {
+        if (wrapped)
+          table_tile_loop<true, true>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
+        else
+          table_tile_loop<true, false>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
       } else {
-        pair_table(xi, yi, zi, pj, p, thr, allowed, hist);
+        if (wrapped)
+          table_tile_loop<false, true>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
+        else
+          table_tile_loop<false, false>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
       }
     }
   }
@@ -268,6 +371,28 @@ inline float first_s_reaching(int k, float cutoff, double step, int nbins) {
   return bits_float(hi);
 }
 
+// rint(fl(a / box)) with float32 rounding of the quotient, as the literal kernel.
+inline float literal_rint_quotient(float a, float box) {
+  volatile float q = a / box;
+  return rintf(q);
+}
+
+// Smallest non-negative float32 a with literal_rint_quotient(a, box) >= target
+// (monotone non-decreasing in a; +inf satisfies it).
+inline float first_a_reaching(float target, float box) {
+  uint32_t lo = 0u;
+  uint32_t hi = 0x7F800000u;
+  if (literal_rint_quotient(bits_float(lo), box) >= target) return bits_float(lo);
+  while (hi - lo > 1u) {
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    if (literal_rint_quotient(bits_float(mid), box) >= target)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return bits_float(hi);
+}
+
 }  // namespace
 
 struct mdx_rdf_s {
@@ -284,7 +409,7 @@ struct mdx_rdf_s {
   int lds_thr_words = 0;
   size_t lds_bytes = 0;
   DeviceBuffer d_pairs, d_pairs_shard, d_hist, d_thresholds, d_slot_species, d_slot_atom;
-  DeviceBuffer d_species_ptr, d_frames, d_packed;
+  DeviceBuffer d_species_ptr, d_frames, d_packed, d_wrapped;
   int shard_rank = 0, shard_count = 1;
   int64_t n_pairs_shard = 0;
   std::vector<const void *> uploaded_ptrs;  // content of d_species_ptr
@@ -353,6 +478,17 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   const float width = cutoff - 0.0f;
   p.step = static_cast<double>(width) / static_cast<double>(nbins);
   p.inv_step = static_cast<float>(static_cast<double>(nbins) / static_cast<double>(width));
+  // |approximate - exact bin position| <= position * (1 ulp sqrt + 2 roundings), kept
+  // below position * 2^-21; positions never exceed nbins (+1).
+  {
+    double eps = (static_cast<double>(nbins) + 2.0) * 0x1p-21 + 0x1p-20;
+    if (eps > 0.5) eps = 0.5;  // then every pair consults the thresholds
+    p.edge_half = static_cast<float>(0.5 - eps);
+  }
+  for (int c = 0; c < 3; ++c) {
+    p.t_wrap[c] = first_a_reaching(1.0f, box[c]);
+    p.t_far[c] = first_a_reaching(2.0f, box[c]);
+  }
 
   // slots: per species, the atoms that take part, padded to whole tiles
   const bool strict = (flags & MDX_RDF_STRICT_REFERENCE_MASKS) != 0u;
@@ -399,7 +535,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 
   // LDS budget
   const bool literal = (flags & MDX_RDF_LITERAL_KERNEL) != 0u;
-  h->lds_hist_words = (nbins + 3) & ~3;
+  h->lds_hist_words = ((nbins + 3) & ~3) + 64;  // bins, padding, one dummy slot per lane
   h->lds_thr_words = literal ? 0 : ((nbins + 1 + 3) & ~3);
   h->lds_bytes = 4 * static_cast<size_t>(h->lds_hist_words + h->lds_thr_words) +
                  sizeof(float4) * kTile;
@@ -540,12 +676,15 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 32768) chunk = 32768;
   MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(chunk)));
+  MDX_TRY(h->d_wrapped.reserve(sizeof(int32_t) * static_cast<size_t>(chunk)));
 
   const bool literal = (h->flags & MDX_RDF_LITERAL_KERNEL) != 0u;
   for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = static_cast<int>(std::min<int64_t>(chunk, n_frames - f0));
     dim3 pgrid(static_cast<unsigned>(ceil_div(h->n_pad, 64)),
                static_cast<unsigned>(ceil_div(nf, 16)));
+    {
+    KernelTimer timer(MDX_SLOT_RDF_PACK, stream);
     if (dtype == MDX_F32) {
       hipLaunchKernelGGL(rdf_pack_kernel<float>, pgrid, dim3(256), 0, stream,
                          h->d_species_ptr.as<const void *>(),
@@ -559,8 +698,15 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
                          d_frames ? d_frames + f0 : nullptr, f0, frame_stride, nf, h->n_pad,
                          h->d_packed.as<float>());
     }
+    }
     MDX_HIP(hipGetLastError());
     if (h->n_pairs_shard == 0) continue;
+    if (!literal) {
+      hipLaunchKernelGGL(rdf_extent_kernel, dim3(static_cast<unsigned>(nf)), dim3(256), 0,
+                         stream, h->d_packed.as<float>(), h->n_pad, h->params,
+                         h->d_wrapped.as<int32_t>());
+      MDX_HIP(hipGetLastError());
+    }
     // frames per block: large enough to amortise the histogram flush, small
     // enough to keep several thousand blocks in flight
     int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 8192;
@@ -568,17 +714,20 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
     if (fpg > kMaxFramesPerGroup) fpg = kMaxFramesPerGroup;
     dim3 grid(static_cast<unsigned>(h->n_pairs_shard),
               static_cast<unsigned>(ceil_div(nf, fpg)));
+    KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
     if (literal) {
       hipLaunchKernelGGL(rdf_tile_kernel<true>, grid, dim3(kTile), h->lds_bytes, stream,
                          h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
                          h->d_pairs_shard.as<TilePair>(), h->params,
-                         static_cast<const float *>(nullptr), h->lds_hist_words,
+                         static_cast<const float *>(nullptr),
+                         static_cast<const int32_t *>(nullptr), h->lds_hist_words,
                          h->lds_thr_words, h->d_hist.as<unsigned long long>());
     } else {
       hipLaunchKernelGGL(rdf_tile_kernel<false>, grid, dim3(kTile), h->lds_bytes, stream,
                          h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
                          h->d_pairs_shard.as<TilePair>(), h->params,
-                         h->d_thresholds.as<float>(), h->lds_hist_words, h->lds_thr_words,
+                         h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
+                         h->lds_hist_words, h->lds_thr_words,
                          h->d_hist.as<unsigned long long>());
     }
     MDX_HIP(hipGetLastError());

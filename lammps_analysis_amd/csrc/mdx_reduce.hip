@@ -266,6 +266,8 @@ int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_at
   const ChunkPlan plan = plan_chunks(n_atoms, threads_needed);
   MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * row_len));
   dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  {
+  KernelTimer timer(MDX_SLOT_ATOM_SUM, stream);
   if (dtype == MDX_F32) {
     const float *xf = static_cast<const float *>(dx);
     if (aligned)
@@ -286,6 +288,7 @@ int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_at
       hipLaunchKernelGGL((weighted_sum_kernel<double, 1>), grid, dim3(kThreads), 0, stream,
                          xd, dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
                          partial.as<double>());
+  }
   }
   MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, row_len, out, out_location,

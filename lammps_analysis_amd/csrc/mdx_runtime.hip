@@ -46,9 +46,74 @@ int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging
   return MDX_OK;
 }
 
+// ---- kernel profiling
+static bool g_profiling = false;
+struct EventPair {
+  hipEvent_t start, stop;
+};
+static std::vector<EventPair> g_pending[MDX_NUM_SLOTS];
+static double g_total_ms[MDX_NUM_SLOTS] = {0};
+static int64_t g_launches[MDX_NUM_SLOTS] = {0};
+
+KernelTimer::KernelTimer(int slot, hipStream_t stream) : slot_(slot), stream_(stream) {
+  if (!g_profiling || slot < 0 || slot >= MDX_NUM_SLOTS) return;
+  if (hipEventCreate(&start_) != hipSuccess) {
+    start_ = nullptr;
+    return;
+  }
+  if (hipEventCreate(&stop_) != hipSuccess) {
+    (void)hipEventDestroy(start_);
+    start_ = stop_ = nullptr;
+    return;
+  }
+  (void)hipEventRecord(start_, stream_);
+}
+
+KernelTimer::~KernelTimer() {
+  if (start_ == nullptr) return;
+  (void)hipEventRecord(stop_, stream_);
+  g_pending[slot_].push_back({start_, stop_});
+}
+
+static void drain_slot(int slot) {
+  for (EventPair &p : g_pending[slot]) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(p.stop) == hipSuccess &&
+        hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      g_total_ms[slot] += ms;
+      g_launches[slot] += 1;
+    }
+    (void)hipEventDestroy(p.start);
+    (void)hipEventDestroy(p.stop);
+  }
+  g_pending[slot].clear();
+}
+
 }  // namespace mdx
 
 using namespace mdx;
+
+extern "C" int mdx_profile_enable(int on) {
+  g_profiling = (on != 0);
+  return MDX_OK;
+}
+
+extern "C" int mdx_profile_reset(void) {
+  for (int s = 0; s < MDX_NUM_SLOTS; ++s) {
+    drain_slot(s);
+    g_total_ms[s] = 0.0;
+    g_launches[s] = 0;
+  }
+  return MDX_OK;
+}
+
+extern "C" int mdx_profile_query(int slot, double *total_ms, int64_t *launches) {
+  MDX_REQUIRE(slot >= 0 && slot < MDX_NUM_SLOTS, "slot out of range");
+  drain_slot(slot);
+  if (total_ms) *total_ms = g_total_ms[slot];
+  if (launches) *launches = g_launches[slot];
+  return MDX_OK;
+}
 
 struct mdx_event_s {
   hipEvent_t ev;

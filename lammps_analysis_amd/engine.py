@@ -91,7 +91,12 @@ class DeviceArray:
 
 def uniform_fill_reference(n: int, seed: int, lo: float, hi: float, start: int = 0) -> np.ndarray:
     """NumPy restatement of ``mdx_fill_uniform_f32`` for elements start..start+n-1."""
-    i = np.arange(start, start + n, dtype=np.uint64)
+    return uniform_fill_at(np.arange(start, start + n, dtype=np.uint64), seed, lo, hi)
+
+
+def uniform_fill_at(index: np.ndarray, seed: int, lo: float, hi: float) -> np.ndarray:
+    """Values ``mdx_fill_uniform_f32`` writes at the given flat element indices."""
+    i = np.asarray(index, dtype=np.uint64)
     with np.errstate(over="ignore"):
         z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (i + np.uint64(1))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
@@ -375,3 +380,26 @@ def msd_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: in
         int(win_end), tau.ctypes.data_as(_lib.c_i32_p), len(tau), float(scale),
         msd.ctypes.data_as(_lib.c_f64_p)))
     return msd
+
+
+# ------------------------------------------------------------------ profiling
+
+SLOTS = {"rdf_pack": 0, "rdf_tile": 1, "atom_sum": 2, "acf_partial": 3, "acf_finish": 4,
+         "msd": 5}
+
+
+def profile_enable(on: bool = True) -> None:
+    """Bracket every kernel launch with HIP events on the library stream."""
+    check(_lib.load().mdx_profile_enable(1 if on else 0))
+
+
+def profile_reset() -> None:
+    check(_lib.load().mdx_profile_reset())
+
+
+def profile_query(slot: str):
+    """(total kernel milliseconds, launches) of one slot since the last reset."""
+    ms = ctypes.c_double(0.0)
+    n = ctypes.c_int64(0)
+    check(_lib.load().mdx_profile_query(SLOTS[slot], ctypes.byref(ms), ctypes.byref(n)))
+    return float(ms.value), int(n.value)

@@ -156,3 +156,36 @@ def test_medium_system_table_equals_literal(gpu):
     np.testing.assert_array_equal(tab, lit)
     ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
     np.testing.assert_array_equal(lit, ref)
+
+
+def test_mixed_wrapped_and_unwrapped_frames(gpu):
+    """Frames inside the box take the threshold minimum-image path, frames with
+    atoms several images away the general one; both in one call."""
+    rng = np.random.default_rng(6)
+    n_per_species = [270, 300]
+    box = [10.0, 12.0, 9.0]
+    pos = _positions(rng, n_per_species, 6, box)
+    for p in pos:
+        p[:, 1] += np.float32(23.0) * rng.integers(-2, 3, size=(p.shape[0], 3)).astype(np.float32)
+        p[5, 4, 0] = np.float32(1.0e4)
+    cutoff = np.float32(4.4)
+    nbins = 440
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
+    got = _gpu_hist(gpu, pos, n_per_species, box, cutoff, nbins)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_box_edge_coordinates_half_box_ties(gpu):
+    """Atoms exactly half a box apart (rint ties) and exactly at 0 / L."""
+    box = [8.0, 8.0, 8.0]
+    grid = np.array([0.0, 4.0, 8.0, np.nextafter(np.float32(4.0), np.float32(0)),
+                     np.nextafter(np.float32(4.0), np.float32(9)), 2.0, 6.0], dtype=np.float32)
+    pts = np.array([[x, y, z] for x in grid for y in grid for z in grid], dtype=np.float32)
+    pos = [np.ascontiguousarray(np.concatenate([np.zeros((1, 3), np.float32), pts])[:, None, :])]
+    n_per_species = [pos[0].shape[0]]
+    cutoff = np.float32(7.5)
+    nbins = 300
+    ref = c_oracle.rdf_hist(pos[0], n_per_species, box, cutoff, nbins)
+    for literal in (True, False):
+        got = _gpu_hist(gpu, pos, n_per_species, box, cutoff, nbins, literal=literal)
+        np.testing.assert_array_equal(got, ref)
