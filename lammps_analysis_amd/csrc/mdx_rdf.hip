@@ -200,34 +200,52 @@ __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict
 // pair_literal for every input; see the file header for the argument.
 //   thr[k], k = 0..nbins: smallest float32 squared distance that falls into a bin
 //   >= k (thr[0] = 0, thr[nbins] = +inf); p.s_cut: smallest squared distance that
-//   fails d < cutoff.  Lanes without a pair to count add into a per-lane dummy slot
-//   behind the histogram, which keeps the loop free of divergent branches.
+//   fails d < cutoff.
+// The j-atoms are the same for every lane, so they are fetched with wave-uniform
+// (scalar) loads straight from the packed image, four atoms per component and
+// request, one iteration ahead of their use; LDS is left to the histogram.
 template <bool kDiag, bool kWrapped>
 __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
-                                                const float4 *__restrict__ tile,
+                                                const float *__restrict__ xj,
+                                                const float *__restrict__ yj,
+                                                const float *__restrict__ zj,
                                                 uint32_t *__restrict__ hist,
                                                 const float *__restrict__ thr,
-                                                const RdfParams &p, int tid, int dummy) {
-  const int j_begin = kDiag ? (tid & ~63) : 0;
+                                                const RdfParams &p, int tid) {
+  // In a diagonal tile lane t only pairs with j > t: a wave skips the j-atoms
+  // below its first lane.
+  const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
+  float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
+  float4 ny = *reinterpret_cast<const float4 *>(yj + j_begin);
+  float4 nz = *reinterpret_cast<const float4 *>(zj + j_begin);
   for (int j0 = j_begin; j0 < kTile; j0 += 4) {
+    const float4 cx = nx, cy = ny, cz = nz;
+    // prefetch; the last iteration re-reads its own atoms instead of running past
+    // the tile
+    const int jn = (j0 + 4 < kTile) ? j0 + 4 : j0;
+    nx = *reinterpret_cast<const float4 *>(xj + jn);
+    ny = *reinterpret_cast<const float4 *>(yj + jn);
+    nz = *reinterpret_cast<const float4 *>(zj + jn);
+    const float pxs[4] = {cx.x, cx.y, cx.z, cx.w};
+    const float pys[4] = {cy.x, cy.y, cy.z, cy.w};
+    const float pzs[4] = {cz.x, cz.y, cz.z, cz.w};
     float s[4];
     int b[4];
     bool keep[4], near_edge[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float4 pj = tile[j0 + u];
       float ax, ay, az;
       if (kWrapped) {
-        ax = fabsf(pj.x - xi);
-        ay = fabsf(pj.y - yi);
-        az = fabsf(pj.z - zi);
+        ax = fabsf(pxs[u] - xi);
+        ay = fabsf(pys[u] - yi);
+        az = fabsf(pzs[u] - zi);
         ax = ax - ((ax >= p.t_wrap[0]) ? p.box[0] : 0.0f);
         ay = ay - ((ay >= p.t_wrap[1]) ? p.box[1] : 0.0f);
         az = az - ((az >= p.t_wrap[2]) ? p.box[2] : 0.0f);
       } else {
-        ax = pj.x - xi;
-        ay = pj.y - yi;
-        az = pj.z - zi;
+        ax = pxs[u] - xi;
+        ay = pys[u] - yi;
+        az = pzs[u] - zi;
         ax = ax - exact_rint_quotient(ax, p.box[0], p.inv_box[0]) * p.box[0];
         ay = ay - exact_rint_quotient(ay, p.box[1], p.inv_box[1]) * p.box[1];
         az = az - exact_rint_quotient(az, p.box[2], p.inv_box[2]) * p.box[2];
@@ -255,14 +273,16 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) atomicAdd(&hist[keep[u] ? b[u] : dummy], 1u);
+    for (int u = 0; u < 4; ++u) {
+      if (keep[u]) atomicAdd(&hist[b[u]], 1u);
+    }
   }
 }
 
 // ---------------------------------------------------------------- tile kernel
 
-// LDS layout: uint32 hist[lds_hist_words] (bins, padding, 64 dummy slots) |
-// float thresholds[lds_thr_words] (table kernel only) | float4 tile[kTile].
+// LDS layout: uint32 hist[lds_hist_words] | float thresholds[lds_thr_words] (table
+// kernel) | float4 tile[kTile] (literal kernel).
 template <bool kLiteral>
 __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_group,
@@ -284,21 +304,23 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
   if (!kLiteral) {
     for (int b = tid; b <= p.nbins; b += kTile) thr[b] = g_thresholds[b];
   }
-  const int dummy = lds_hist_words - 64 + (tid & 63);
+  __syncthreads();
 
   const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
-  const int64_t slot_j = static_cast<int64_t>(tp.tile_j) * kTile + tid;
+  const int64_t tile_j0 = static_cast<int64_t>(tp.tile_j) * kTile;
 
   for (int f = f_begin; f < f_end; ++f) {
     const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
     const float xi = X[slot_i];
     const float yi = X[n_pad + slot_i];
     const float zi = X[2 * n_pad + slot_i];
-    const float4 mine = make_float4(X[slot_j], X[n_pad + slot_j], X[2 * n_pad + slot_j], 0.0f);
-    __syncthreads();  // previous frame's tile reads are complete (and LDS init)
-    tile[tid] = mine;
-    __syncthreads();
     if (kLiteral) {
+      const int64_t slot_j = tile_j0 + tid;
+      const float4 mine =
+          make_float4(X[slot_j], X[n_pad + slot_j], X[2 * n_pad + slot_j], 0.0f);
+      __syncthreads();  // the previous frame's tile reads are complete
+      tile[tid] = mine;
+      __syncthreads();
       // In a diagonal tile lane t only pairs with j > t: a wave can skip every j
       // that is not above its first lane.
       const int j_start = tp.diagonal ? ((tid & ~63) + 1) : 0;
@@ -308,17 +330,20 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
         pair_literal(xi, yi, zi, tile[j], p, allowed, hist);
       }
     } else {
+      const float *xj = X + tile_j0;
+      const float *yj = xj + n_pad;
+      const float *zj = yj + n_pad;
       const bool wrapped = frame_wrapped[f] != 0;
       if (tp.diagonal) {
         if (wrapped)
-          table_tile_loop<true, true>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
+          table_tile_loop<true, true>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
         else
-          table_tile_loop<true, false>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
+          table_tile_loop<true, false>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
       } else {
         if (wrapped)
-          table_tile_loop<false, true>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
+          table_tile_loop<false, true>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
         else
-          table_tile_loop<false, false>(xi, yi, zi, tile, hist, thr, p, tid, dummy);
+          table_tile_loop<false, false>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
       }
     }
   }
@@ -535,10 +560,10 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 
   // LDS budget
   const bool literal = (flags & MDX_RDF_LITERAL_KERNEL) != 0u;
-  h->lds_hist_words = ((nbins + 3) & ~3) + 64;  // bins, padding, one dummy slot per lane
+  h->lds_hist_words = (nbins + 3) & ~3;
   h->lds_thr_words = literal ? 0 : ((nbins + 1 + 3) & ~3);
   h->lds_bytes = 4 * static_cast<size_t>(h->lds_hist_words + h->lds_thr_words) +
-                 sizeof(float4) * kTile;
+                 (literal ? sizeof(float4) * kTile : 0);
   if (h->lds_bytes > 160 * 1024)
     return fail(MDX_ERR_INVALID_ARGUMENT,
                 "nbins=%d needs %zu bytes of LDS per workgroup, more than the 160 KiB of a "
