@@ -61,7 +61,8 @@ struct RdfParams {
   float cutoff;        // float32 cutoff (literal kernel)
   float s_cut;         // smallest float32 s with sqrtf(s) >= cutoff (table kernel)
   float inv_step;      // float32(nbins / cutoff), approximate bin scale
-  float edge_half;     // 0.5 - error bound of the approximate bin position
+  float edge_eps;      // error bound of the approximate bin position
+  float edge_eps2;     // twice that
   double step;         // double(cutoff - 0.0f) / double(nbins)
   int nbins;
 };
@@ -188,9 +189,9 @@ __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict
         mn = fminf(mn, s_min[c][w]);
         mx = fmaxf(mx, s_max[c][w]);
       }
-      // no atom at all: mx - mn = -inf - inf = -inf < t_far
+      // no atom at all: mx - mn = -inf - inf = -inf, counts as wrapped
       const float extent = mx - mn;
-      ok = ok && (extent < p.t_far[c]);
+      ok = ok && (extent < p.t_far[c]) && (p.t_far[c] > 0.0f);
     }
     wrapped[f] = ok ? 1 : 0;
   }
@@ -236,12 +237,14 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
     for (int u = 0; u < 4; ++u) {
       float ax, ay, az;
       if (kWrapped) {
+        // |r| >= t_wrap = nextafter(L/2) selects L - |r| (same magnitude as the
+        // literal |r| - L); below it L - |r| >= |r|, so the minimum is exact.
         ax = fabsf(pxs[u] - xi);
         ay = fabsf(pys[u] - yi);
         az = fabsf(pzs[u] - zi);
-        ax = ax - ((ax >= p.t_wrap[0]) ? p.box[0] : 0.0f);
-        ay = ay - ((ay >= p.t_wrap[1]) ? p.box[1] : 0.0f);
-        az = az - ((az >= p.t_wrap[2]) ? p.box[2] : 0.0f);
+        ax = fminf(ax, p.box[0] - ax);
+        ay = fminf(ay, p.box[1] - ay);
+        az = fminf(az, p.box[2] - az);
       } else {
         ax = pxs[u] - xi;
         ay = pys[u] - yi;
@@ -253,9 +256,11 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
       s[u] = (ax * ax + ay * ay) + az * az;
       keep[u] = s[u] < p.s_cut;
       if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
-      const float t = __builtin_amdgcn_sqrtf(s[u]) * p.inv_step;
+      // bin position shifted up by the error bound eps: away from an edge its
+      // integer part is the bin, and "within eps of an edge" is fract < 2 eps
+      const float t = __builtin_fmaf(__builtin_amdgcn_sqrtf(s[u]), p.inv_step, p.edge_eps);
       b[u] = static_cast<int>(t);
-      near_edge[u] = fabsf(__builtin_amdgcn_fractf(t) - 0.5f) > p.edge_half;
+      near_edge[u] = __builtin_amdgcn_fractf(t) < p.edge_eps2;
     }
     const bool fix = (keep[0] && near_edge[0]) || (keep[1] && near_edge[1]) ||
                      (keep[2] && near_edge[2]) || (keep[3] && near_edge[3]);
@@ -507,12 +512,17 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   // below position * 2^-21; positions never exceed nbins (+1).
   {
     double eps = (static_cast<double>(nbins) + 2.0) * 0x1p-21 + 0x1p-20;
-    if (eps > 0.5) eps = 0.5;  // then every pair consults the thresholds
-    p.edge_half = static_cast<float>(0.5 - eps);
+    if (eps > 0.25) eps = 0.5;  // then every pair consults the thresholds
+    p.edge_eps = static_cast<float>(eps);
+    p.edge_eps2 = static_cast<float>(2.0 * eps);
   }
   for (int c = 0; c < 3; ++c) {
     p.t_wrap[c] = first_a_reaching(1.0f, box[c]);
     p.t_far[c] = first_a_reaching(2.0f, box[c]);
+    // The wrapped-frame path takes min(|r|, L - |r|), which equals the literal
+    // result only if no float lies strictly between L/2 and t_wrap (always the case
+    // for IEEE float32; checked anyway).  Otherwise no frame may use that path.
+    if (p.t_wrap[c] != nextafterf(box[c] * 0.5f, INFINITY)) p.t_far[c] = 0.0f;
   }
 
   // slots: per species, the atoms that take part, padded to whole tiles
