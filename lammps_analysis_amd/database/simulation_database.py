@@ -1,0 +1,297 @@
+"""Trajectory data model and the simulation database.
+
+The data-model classes (``PropertyInfo``, ``SpeciesInfo``, ``MoleculeInfo``,
+``TrajectoryMetadata``, ``TrajectoryChunkData``) carry the same fields as
+mdsuite/database/simulation_database.py:43-227 of the reference, so that ingest
+code written against it keeps working.
+
+``Database`` keeps the reference's method surface (:230-702) on a different
+storage engine.  The reference stores every dataset in one gzip-chunked HDF5 file
+as float32 with the layout ``[n_particles, n_configurations, n_dims]``; h5py is
+not a dependency here, and a compressed container is the wrong source for a GPU
+that wants to stream frame blocks.  Each dataset is therefore one raw
+``.npy`` file (float32, same layout, memory-mapped) inside a directory, with a
+small JSON index holding shapes and the append position.  Reads return views of
+the memory map, so a batch goes from the page cache to the device without an
+intermediate copy.
+"""
+from __future__ import annotations
+
+import dataclasses
+import json
+import logging
+import pathlib
+import typing
+from typing import List
+
+import numpy as np
+
+log = logging.getLogger(__name__)
+
+STORAGE_DTYPE = np.float32  # the reference's h5py datasets default to float32 (:491-497)
+
+
+@dataclasses.dataclass(frozen=True)
+class PropertyInfo:
+    """Name and dimensionality of a trajectory property, e.g. ("Positions", 3)."""
+
+    name: str
+    n_dims: int
+
+
+@dataclasses.dataclass
+class SpeciesInfo:
+    """A species: its name, particle count, recorded properties, mass and charge."""
+
+    name: str
+    n_particles: int
+    properties: List[PropertyInfo]
+    mass: float = None
+    charge: float = 0
+
+    def __eq__(self, other):
+        if len(self.properties) != len(other.properties):
+            return False
+        same = (self.name == other.name and self.n_particles == other.n_particles
+                and self.mass == other.mass and self.charge == other.charge)
+        return same and all(a == b for a, b in zip(self.properties, other.properties))
+
+
+@dataclasses.dataclass
+class MoleculeInfo(SpeciesInfo):
+    """A molecule species; ``groups`` maps molecule index -> {species: [atom ids]}."""
+
+    groups: dict = None
+
+    def __eq__(self, other):
+        if self.groups != other.groups:
+            return False
+        return super().__eq__(other)
+
+
+@dataclasses.dataclass
+class TrajectoryMetadata:
+    """What must be known about a trajectory before its database can be laid out."""
+
+    n_configurations: int
+    species_list: List[SpeciesInfo]
+    box_l: list = None
+    sample_rate: int = 1
+    sample_step: float = None
+    temperature: float = None
+    simulation_data: dict = dataclasses.field(default_factory=dict)
+
+
+class TrajectoryChunkData:
+    """A block of configurations on its way from a file reader to the database.
+
+    Data is held per species and property as ``[chunk_size, n_particles, n_dims]``
+    (time first, as file readers produce it).
+    """
+
+    def __init__(self, species_list: List[SpeciesInfo], chunk_size: int):
+        self.chunk_size = chunk_size
+        self.species_list = species_list
+        self._data = {
+            sp.name: {prop.name: np.zeros((chunk_size, sp.n_particles, prop.n_dims))
+                      for prop in sp.properties}
+            for sp in species_list
+        }
+
+    def add_data(self, data: np.ndarray, config_idx, species_name, property_name):
+        """Store ``data`` ``[n_configs, n_particles, n_dims]`` from ``config_idx`` on."""
+        data = np.asarray(data)
+        n_configs = len(data)
+        self._data[species_name][property_name][config_idx:config_idx + n_configs, :, :] = data
+
+    def get_data(self):
+        return self._data
+
+
+class Database:
+    """Directory-of-``.npy`` store with the reference ``Database`` interface."""
+
+    INDEX = "index.json"
+
+    def __init__(self, path: typing.Union[str, pathlib.Path] = "database"):
+        self.path = pathlib.Path(path).as_posix() if isinstance(path, pathlib.Path) else path
+        self._root = pathlib.Path(self.path)
+
+    # ------------------------------------------------------------------ index
+
+    def _load_index(self) -> dict:
+        index_file = self._root / self.INDEX
+        if not index_file.exists():
+            return {}
+        with open(index_file) as fh:
+            return json.load(fh)
+
+    def _save_index(self, index: dict) -> None:
+        self._root.mkdir(parents=True, exist_ok=True)
+        tmp = self._root / (self.INDEX + ".tmp")
+        with open(tmp, "w") as fh:
+            json.dump(index, fh)
+        tmp.replace(self._root / self.INDEX)
+
+    def _file(self, dataset: str) -> pathlib.Path:
+        return self._root / (dataset.strip("/").replace("/", "__") + ".npy")
+
+    # --------------------------------------------------------------- structure
+
+    @staticmethod
+    def _build_path_input(structure: dict) -> dict:
+        """{'Na': {'Forces': shape}} -> {'Na/Forces': shape}; flat entries pass through."""
+        architecture = {}
+        for group, value in structure.items():
+            if isinstance(value, dict):
+                for subgroup, shape in value.items():
+                    architecture[f"{group}/{subgroup}"] = shape
+            else:
+                architecture[group] = value
+        return architecture
+
+    def database_exists(self) -> bool:
+        return (self._root / self.INDEX).exists()
+
+    def initialize_database(self, structure: dict):
+        self.add_dataset(self._build_path_input(structure))
+
+    def add_dataset(self, architecture: dict):
+        """Create zero-filled datasets ``{path: shape}`` (append position 0)."""
+        index = self._load_index()
+        for dataset, shape in architecture.items():
+            if not isinstance(shape, tuple):
+                raise TypeError("Invalid input for dataset generation")
+            dataset = dataset.strip("/")
+            shape = tuple(int(s) for s in shape)
+            self._root.mkdir(parents=True, exist_ok=True)
+            mm = np.lib.format.open_memmap(self._file(dataset), mode="w+",
+                                           dtype=STORAGE_DTYPE, shape=shape)
+            del mm
+            index[dataset] = {"shape": list(shape), "starting_index": 0}
+        self._save_index(index)
+
+    def resize_datasets(self, structure: dict):
+        """Grow datasets along the configuration axis by the given amounts; unknown
+        datasets are created (simulation_database.py:380-418 of the reference)."""
+        architecture = self._build_path_input(structure)
+        index = self._load_index()
+        for dataset, info in architecture.items():
+            if not isinstance(info, tuple):
+                raise TypeError("Invalid input for dataset generation")
+            dataset = dataset.strip("/")
+            if dataset not in index:
+                self.add_dataset({dataset: info})
+                index = self._load_index()
+                continue
+            axis = 0 if len(info[:-1]) == 1 else 1
+            old = np.load(self._file(dataset), mmap_mode="r")
+            new_shape = list(old.shape)
+            new_shape[axis] = old.shape[axis] + int(info[axis])
+            tmp = self._file(dataset).with_suffix(".grow.npy")
+            grown = np.lib.format.open_memmap(tmp, mode="w+", dtype=STORAGE_DTYPE,
+                                              shape=tuple(new_shape))
+            selector = [slice(None)] * len(new_shape)
+            selector[axis] = slice(0, old.shape[axis])
+            grown[tuple(selector)] = old
+            del grown, old
+            tmp.replace(self._file(dataset))
+            index[dataset]["shape"] = new_shape
+        self._save_index(index)
+
+    # -------------------------------------------------------------------- I/O
+
+    def add_data(self, chunk: TrajectoryChunkData):
+        """Append a chunk at every dataset's append position, transposing from the
+        chunk's time-first layout to the stored ``[particles, configurations, dims]``."""
+        index = self._load_index()
+        chunk_data = chunk.get_data()
+        for sp_info in chunk.species_list:
+            for prop_info in sp_info.properties:
+                dataset = f"{sp_info.name}/{prop_info.name}"
+                if dataset not in index:
+                    raise KeyError(f"dataset '{dataset}' is not in the database")
+                write_data = chunk_data[sp_info.name][prop_info.name]
+                start = index[dataset]["starting_index"]
+                stop = start + chunk.chunk_size
+                mm = np.load(self._file(dataset), mmap_mode="r+")
+                if mm.ndim == 2:
+                    mm[start:stop, :] = write_data[:, 0, :]
+                elif mm.ndim == 3:
+                    mm[:, start:stop, :] = np.swapaxes(write_data, 0, 1)
+                else:
+                    raise ValueError("dataset shape must be either (n_part,n_config,n_dim) "
+                                     "or (n_config, n_dim)")
+                mm.flush()
+                del mm
+                index[dataset]["starting_index"] = stop
+        self._save_index(index)
+
+    def load_data(self, path_list: list = None, select_slice=np.s_[:],
+                  dictionary: bool = False, scaling: list = None, d_size: int = None,
+                  dtype=None):
+        """Load slices of datasets: ``{path: array, b"data_size": d_size}``.
+
+        Arrays keep the stored float32 (``dtype=None``): the reference widens them to
+        float64 on load (:626), the kernels do that widening on the device instead,
+        with identical values.  ``select_slice`` may be a dict ``{species: slice}``.
+        """
+        if scaling is None:
+            scaling = [1 for _ in range(len(path_list))]
+        data = {}
+        for i, item in enumerate(path_list):
+            name = item.decode() if isinstance(item, bytes) else item
+            if isinstance(select_slice, dict):
+                my_slice = select_slice[name.split("/")[0]]
+            else:
+                my_slice = select_slice
+            mm = np.load(self._file(name), mmap_mode="r")
+            try:
+                arr = mm[my_slice]
+            except (TypeError, IndexError):
+                # two fancy indices (atom list and frame list) are applied one by one
+                arr = mm[my_slice[0]][:, my_slice[1], :]
+            arr = np.asarray(arr) if dtype is None else np.asarray(arr, dtype=dtype)
+            if scaling[i] != 1:
+                arr = arr * scaling[i]
+            data[item] = arr
+        data[str.encode("data_size")] = d_size
+        return data
+
+    # -------------------------------------------------------------- inspection
+
+    def check_existence(self, path: str) -> bool:
+        """True if a dataset whose path ends with ``/path`` exists."""
+        if isinstance(path, bytes):
+            path = path.decode()
+        suffix = "/" + path.strip("/")
+        return any(("/" + name).endswith(suffix) for name in self._load_index())
+
+    def get_data_size(self, data_path: str) -> tuple:
+        """(shape[0], shape[1], n_bytes) of a dataset."""
+        if isinstance(data_path, bytes):
+            data_path = data_path.decode()
+        entry = self._load_index()[data_path.strip("/")]
+        shape = entry["shape"]
+        n_bytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(STORAGE_DTYPE).itemsize
+        return shape[0], shape[1], n_bytes
+
+    def get_memory_information(self) -> dict:
+        out = {}
+        for name, entry in self._load_index().items():
+            out[name] = int(np.prod(entry["shape"], dtype=np.int64)) * 4
+        return out
+
+    def get_database_summary(self):
+        return sorted({name.split("/")[0] for name in self._load_index()})
+
+    def change_key_names(self, mapping: dict):
+        """Rename top-level groups."""
+        index = self._load_index()
+        for name in list(index):
+            group, _, rest = name.partition("/")
+            if group in mapping:
+                new_name = f"{mapping[group]}/{rest}" if rest else mapping[group]
+                self._file(name).replace(self._file(new_name))
+                index[new_name] = index.pop(name)
+        self._save_index(index)

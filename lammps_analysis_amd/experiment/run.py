@@ -1,0 +1,97 @@
+"""Dispatch of calculators and transformations.
+
+``experiment.run.<Name>`` / ``project.run.<Name>`` return a fresh calculator bound
+to the experiment(s), or a wrapper that runs a transformation on them, as
+mdsuite/experiment/run.py:58-243 of the reference does.  Only the calculators and
+transformations of the accelerated path exist in this engine.
+"""
+from __future__ import annotations
+
+import functools
+from typing import List
+
+
+class RunComputation:
+    def __init__(self, experiment=None, experiments: List = None):
+        self.experiment = experiment
+        self.experiments = experiments
+        self.kwargs = {"experiment": experiment, "experiments": experiments}
+
+    def exp_wrapper(self, func):
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            return func(*args, **kwargs)
+
+        return wrapper
+
+    def transformation_wrapper(self, func):
+        """Run the transformation on every selected experiment."""
+
+        @functools.wraps(func.run_transformation)
+        def wrapper(*args, **kwargs):
+            if self.experiments is None:
+                self.experiments = [self.experiment]
+            for experiment in self.experiments:
+                experiment.cls_transformation_run(func(), *args, **kwargs)
+
+        return wrapper
+
+    # ------------------------------------------------------- transformations
+
+    @property
+    def IonicCurrent(self):
+        from ..transformations import IonicCurrent
+        return self.transformation_wrapper(IonicCurrent)
+
+    @property
+    def TranslationalDipoleMoment(self):
+        from ..transformations import TranslationalDipoleMoment
+        return self.transformation_wrapper(TranslationalDipoleMoment)
+
+    @property
+    def MomentumFlux(self):
+        from ..transformations import MomentumFlux
+        return self.transformation_wrapper(MomentumFlux)
+
+    @property
+    def ThermalFlux(self):
+        from ..transformations import ThermalFlux
+        return self.transformation_wrapper(ThermalFlux)
+
+    # ----------------------------------------------------------- calculators
+
+    def _calculator(self, name: str):
+        from .. import calculators
+        return self.exp_wrapper(getattr(calculators, name))(**self.kwargs)
+
+    @property
+    def RadialDistributionFunction(self):
+        return self._calculator("RadialDistributionFunction")
+
+    @property
+    def GreenKuboIonicConductivity(self):
+        return self._calculator("GreenKuboIonicConductivity")
+
+    @property
+    def GreenKuboDiffusionCoefficients(self):
+        return self._calculator("GreenKuboDiffusionCoefficients")
+
+    @property
+    def GreenKuboViscosity(self):
+        return self._calculator("GreenKuboViscosity")
+
+    @property
+    def GreenKuboThermalConductivity(self):
+        return self._calculator("GreenKuboThermalConductivity")
+
+    @property
+    def GreenKuboViscosityFlux(self):
+        return self._calculator("GreenKuboViscosityFlux")
+
+    @property
+    def EinsteinDiffusionCoefficients(self):
+        return self._calculator("EinsteinDiffusionCoefficients")
+
+    @property
+    def EinsteinHelfandIonicConductivity(self):
+        return self._calculator("EinsteinHelfandIonicConductivity")

@@ -427,7 +427,6 @@ def green_kubo_windowed_flux(series: np.ndarray, data_range: int, correlation_ti
         ensemble = series[:, origin:origin + data_range]
         jacf = data_range * np.sum(auto_correlation(ensemble, axis=1), axis=-1)[0]
         jacf_sum += jacf
-        sigma.append(np.trapz(jacf[:integration_range], x=time[:integration_range])
-                     if hasattr(np, "trapz") else
-                     np.trapezoid(jacf[:integration_range], x=time[:integration_range]))
+        trapezoid = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
+        sigma.append(trapezoid(jacf[:integration_range], x=time[:integration_range]))
     return jacf_sum, np.array(sigma)
