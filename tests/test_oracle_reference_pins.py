@@ -1,0 +1,208 @@
+"""The oracle against what the reference's own tests hold for this path (CPU only).
+
+Restates, with NumPy inputs, the offline-reproducible checks of the reference:
+  CI/unit_tests/memory_manager/test_memory_manager.py:128-228   (exact integers)
+  CI/unit_tests/transformations/test_transformations.py:59-79,124-144
+  CI/unit_tests/utils/test_calculator_helper_methods.py:42-133
+  CI/integration_tests/calculators/test_green_kubo_self_diffusion_coefficients.py:45-117
+  CI/integration_tests/calculators/test_einstein_diffusion_coefficients.py:45-99
+The RDF has no offline check in the reference; its oracle is cross-checked between the
+NumPy restatement (materialised index lists, gathers, masks) and the C restatement
+(pair loops) and against hand-computable cases.
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import correlation as orc
+from oracle import rdf as orc_rdf
+
+
+@dataclasses.dataclass
+class _Units:
+    time: float = 1.0
+    length: float = 1.0
+
+    @property
+    def volume(self):
+        return self.length**3
+
+
+# ------------------------------------------------------------------ batching
+
+def test_batch_size_integers_of_the_reference():
+    # data_size=500, rows=10, columns=10, fraction 0.5 of 50000 bytes, linear x10
+    assert orc.get_batch_size([500], 10, 50000, 0.5, orc.linear_scale_function,
+                              {"scale_factor": 10}) == (10, 1, 0)
+    # data_size=500, rows=11, columns=13, fraction 1.0 of 50 bytes
+    assert orc.get_batch_size([500], 13, 50, 1.0, orc.linear_scale_function,
+                              {"scale_factor": 10}) == (1, 13, 0)
+    assert orc.get_ensemble_loop(50, 10, 5) == 8
+    assert orc.quadratic_scale_function(10, 2, 2) == 800
+
+
+def test_window_origins_exclude_the_last_admissible_one():
+    assert orc.window_starts(100, 10, 1) == list(range(90))
+    assert orc.window_starts(100, 10, 7) == [7 * w for w in range(12)]
+    assert orc.window_starts(10, 10, 1) == [0]      # clip(..., 1, None)
+    assert orc.window_starts(5, 10, 1) == [0]
+
+
+def test_tau_value_forms():
+    tau, d = orc.handle_tau_values(np.s_[:], 6)
+    assert tau.tolist() == [0, 1, 2, 3, 4, 5] and d == 6
+    tau, d = orc.handle_tau_values(4, 10)
+    assert tau.tolist() == [0, 3, 6, 9] and d == 10
+    tau, d = orc.handle_tau_values([0, 2, 7], 100)
+    assert tau.tolist() == [0, 2, 7] and d == 8
+
+
+# ------------------------------------------------------------ transformations
+
+def test_ionic_current_and_dipole_identity():
+    rng = np.random.default_rng(0)
+    vels, charges = [], []
+    should_be = np.zeros((7, 3))
+    for _ in ("Na", "Cl"):
+        vel = rng.random((5, 7, 3))
+        charge = rng.random()
+        vels.append(vel)
+        charges.append(charge)
+        should_be += np.sum(vel * charge, axis=0)
+    np.testing.assert_array_almost_equal(orc.ionic_current(vels, charges), should_be)
+    np.testing.assert_array_almost_equal(
+        c_oracle.weighted_atom_sum(vels[0].astype(np.float32), charges[0]),
+        np.sum(vels[0].astype(np.float32).astype(np.float64) * charges[0], axis=0))
+
+
+# --------------------------------------------------------------- helper methods
+
+def test_fit_einstein_curve_slopes():
+    x = np.linspace(0, 1000, 1000)
+    popt, _, _, _ = orc.fit_einstein_curve(x, 5 * x + 3, 999)
+    assert popt[0] == pytest.approx(5.0, 0.01)
+    popt, _, _, _ = orc.fit_einstein_curve(x, np.exp(-0.05 * x) * x**2 + 5 * x + 3, 999)
+    assert popt[0] == pytest.approx(5.0, 0.01)
+
+
+# ------------------------------------------------------------- autocorrelation
+
+def test_auto_correlation_equals_direct_unbiased_sum():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(3, 37, 2))
+    got = orc.auto_correlation(x, axis=1)
+    ref = np.zeros_like(got)
+    for m in range(37):
+        ref[:, m] = np.sum(x[:, :37 - m] * x[:, m:], axis=1) / (37 - m)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    tau = np.arange(37)
+    acf = c_oracle.acf_windows(x, 1, 0, 1, tau)
+    np.testing.assert_allclose(acf, ref.sum(axis=(0, 2)), rtol=1e-12, atol=1e-12)
+
+
+def test_langevin_vacf_analytic():
+    """Underdamped Langevin particles: VACF = v_th^2 exp(-t/tau), D known."""
+    diff_coeff, kT, mass, time_step, n_part = 1.2345, 0.7, 1.5, 0.1, 100
+    gamma = kT / diff_coeff
+    relaxation_time = mass / gamma
+    n_step = int(100 * relaxation_time / time_step)
+    vacf_range = int(7 * relaxation_time / time_step)
+    rng = np.random.default_rng(1)
+    force = np.sqrt(2 * kT * gamma / time_step) * rng.normal(size=(n_step, n_part, 3))
+    vel = np.zeros((n_step, n_part, 3))
+    for i in range(1, n_step):
+        vel[i] = vel[i - 1] + time_step * (force[i] - gamma * vel[i - 1]) / mass
+    units = _Units(time=0.0056789, length=0.000007654)
+    res = orc.green_kubo_self_diffusion(np.swapaxes(vel, 0, 1).astype(np.float32), time_step,
+                                        1, units, data_range=vacf_range)
+    t = time_step * np.arange(vacf_range) * units.time
+    v_th = np.sqrt(3 * kT / mass) * units.length / units.time
+    should = v_th**2 * np.exp(-t / (relaxation_time * units.time))
+    np.testing.assert_allclose(res["time"], t, atol=1e-6)
+    np.testing.assert_allclose(res["acf"], should, atol=0.03 * should[0])
+    np.testing.assert_allclose(res["diffusion_coefficient"],
+                               diff_coeff * units.length**2 / units.time, rtol=3e-2)
+
+
+def test_random_walk_msd_analytic():
+    rng = np.random.default_rng(864)
+    diff_coeff, time_step, n_part, n_step, msd_range = 1.2345, 0.1, 200, 3000, 200
+    vel = np.sqrt(2 * diff_coeff / time_step) * rng.normal(size=(n_step, n_part, 3))
+    pos = time_step * np.cumsum(vel, axis=0)
+    units = _Units(time=1.3, length=0.5)
+    stored = np.swapaxes(pos, 0, 1).astype(np.float32)
+    res = orc.einstein_diffusion(stored, time_step, 1, units, data_range=msd_range)
+    t = time_step * np.arange(msd_range) * units.time
+    d_should = diff_coeff * units.length**2 / units.time
+    np.testing.assert_allclose(res["time"], t, atol=1e-5)
+    np.testing.assert_allclose(res["msd"], 6 * d_should * t, rtol=9e-1)
+    np.testing.assert_allclose(res["diffusion_coefficient"], d_should, rtol=2e-1)
+    # C restatement against the NumPy one
+    msd_sum, count, tau = orc.einstein_msd(stored, msd_range)
+    n_win = n_step - msd_range
+    np.testing.assert_allclose(c_oracle.msd_windows(stored, 1, 0, n_win, tau), msd_sum,
+                               rtol=1e-11)
+    assert count == n_win * (n_part + 1)
+
+
+# ------------------------------------------------------------------------ RDF
+
+def test_partial_triu_indices_cover_the_strict_upper_triangle():
+    n = 7
+    seen = []
+    start = 0
+    for m in (3, 3, 1):
+        idx = orc_rdf.get_partial_triu_indices(n, m, start)
+        seen += [(int(i) + start, int(j)) for i, j in idx.T]
+        start += m
+    assert sorted(seen) == [(i, j) for i in range(n) for j in range(i + 1, n)]
+
+
+def test_histogram_fixed_width_rule():
+    values = np.array([0.0, 0.0999, 0.1, 0.95, 1.0, 2.0, -1.0], dtype=np.float32)
+    hist = orc_rdf.histogram_fixed_width(values, [0.0, 1.0], 10)
+    # 0.0, -1.0 (clamped) -> bin 0; 0.0999 -> 0; 0.1 (float32 0.100000001) -> 1;
+    # 0.95 -> 9; 1.0 and 2.0 -> clamped to the last bin
+    assert hist.tolist() == [3, 1, 0, 0, 0, 0, 0, 0, 0, 3]
+
+
+def test_strict_masks_drop_first_atom_of_each_species():
+    # 3 + 3 atoms on a line, all within the cutoff
+    pos = [np.array([[[0.0, 0, 0]], [[1.0, 0, 0]], [[2.0, 0, 0]]], dtype=np.float32),
+           np.array([[[0.5, 0, 0]], [[1.5, 0, 0]], [[2.5, 0, 0]]], dtype=np.float32)]
+    hist = orc_rdf.rdf_histograms(pos, ["A", "B"], [100.0] * 3, np.float32(10.0), 100)
+    assert hist["A_A"].sum() == 1      # only (1,2) of species A
+    assert hist["A_B"].sum() == 4      # {1,2} x {4,5}
+    assert hist["B_B"].sum() == 1
+    c = c_oracle.rdf_hist(np.concatenate(pos, 0), [3, 3], [100.0] * 3, 10.0, 100)
+    assert c.sum(axis=1).tolist() == [1, 4, 1]
+    c_all = c_oracle.rdf_hist(np.concatenate(pos, 0), [3, 3], [100.0] * 3, 10.0, 100,
+                              strict=False)
+    assert c_all.sum(axis=1).tolist() == [3, 9, 3]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_numpy_and_c_rdf_restatements_agree(seed):
+    rng = np.random.default_rng(seed)
+    box = [9.0, 10.0, 11.0]
+    pos = [(rng.random((n, 3, 3)) * np.asarray(box) * 3 - 9).astype(np.float32)
+           for n in (17, 5, 23)]
+    cutoff = np.float32(5.7)
+    ref = orc_rdf.rdf_histograms(pos, ["a", "b", "c"], box, cutoff, 57, rdf_minibatch=11)
+    got = c_oracle.rdf_hist(np.concatenate(pos, 0), [17, 5, 23], box, cutoff, 57)
+    for i, key in enumerate(orc_rdf.key_names(["a", "b", "c"])):
+        np.testing.assert_array_equal(got[i], ref[key].astype(np.uint64))
+
+
+def test_rdf_ideal_gas_is_flat():
+    """Uniform random positions: g(r) ~ 1 away from r = 0 (sanity of prefactor and
+    ideal correction with the non-strict pair set being nearly the same)."""
+    rng = np.random.default_rng(3)
+    box = 20.0
+    pos = [(rng.random((300, 20, 3)) * box).astype(np.float32)]
+    out, _ = orc_rdf.radial_distribution_function(pos, ["Ar"], {"Ar": 300}, [box] * 3, 1e-10,
+                                                  number_of_configurations=20, number_of_bins=50)
+    y = np.asarray(out["Ar_Ar"]["y"])[10:]
+    assert abs(np.mean(y) - 1.0) < 0.05
