@@ -67,21 +67,37 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    dist = None
+    torch = None
+    # BENCH_FORCE_DIST=1 initialises the process group even for one rank (rehearsal
+    # of the multi-rank code path on a single GPU)
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        # plumbing only: rendezvous, barrier, max-reduce, one all-reduce.  torch ships
+        # its own HIP runtime; it has to be loaded before libmdx.so so that both use one
+        # runtime (the loader then resolves libmdx's libamdhip64.so.7 to the loaded one).
+        import torch
+        import torch.distributed as dist
+
     from lammps_analysis_amd import _lib, engine
 
     _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: no HIP device is visible to libmdx")
 
-    dist = None
-    torch = None
-    if world > 1:
-        import torch  # plumbing only: rendezvous, barrier, max-reduce, one all-reduce
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    engine.set_device(local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        # "nccl" is RCCL over xGMI; BENCH_DIST_BACKEND=gloo lets several ranks share
+        # one GPU to rehearse this path on a single-GPU machine
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        device_index = local_rank % _lib.device_count()
+        torch.cuda.set_device(device_index)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        comm_device = "cuda" if backend == "nccl" else "cpu"
+    else:
+        device_index = local_rank
+    engine.set_device(device_index)
 
     def barrier_sync():
         if dist is not None:
@@ -122,7 +138,7 @@ def main() -> None:
     pack_ms, pack_launches = engine.profile_query("rdf_pack")
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -130,7 +146,7 @@ def main() -> None:
     allreduce_ms = None
     hist_total = hist_local
     if dist is not None:
-        h = torch.from_numpy(hist_local.astype(np.int64)).cuda()
+        h = torch.from_numpy(hist_local.astype(np.int64)).to(comm_device)
         torch.cuda.synchronize()
         ta = time.perf_counter()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)

@@ -7,6 +7,11 @@ one all-reduce, the per-window integral statistics by the parallel-variance merg
 ``torch.distributed`` is used only as the transport (backend ``nccl`` is RCCL over
 xGMI on ROCm; ``gloo`` on CPU for tests) and only if the caller has initialised
 it; a single process needs neither torch nor a collective.
+
+PyTorch-ROCm wheels carry their own HIP runtime.  A multi-GPU script must therefore
+``import torch`` (and initialise the process group) before the first calculator or
+engine call, which is when libmdx.so is loaded: the loader then binds libmdx to the
+HIP runtime torch already brought in, instead of starting a second one.
 """
 from __future__ import annotations
 
