@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict
 // The j-atoms are the same for every lane, so they are fetched with wave-uniform
 // (scalar) loads straight from the packed image, four atoms per component and
 // request, one iteration ahead of their use; LDS is left to the histogram.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <bool kDiag, bool kWrapped>
 __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
                                                 const float *__restrict__ xj,
@@ -233,34 +235,60 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
     float s[4];
     int b[4];
     bool keep[4], near_edge[4];
+    if (kWrapped) {
+      // Two j-atoms per packed instruction: the differences, squares, sums and the
+      // bin-position fma each run as one v_pk_*_f32 over an (even, odd) j pair,
+      // with the same per-element rounding as the scalar form.
+      const v2f xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
+      const v2f inv_step2 = {p.inv_step, p.inv_step};
+      const v2f eps2 = {p.edge_eps, p.edge_eps};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float ax, ay, az;
-      if (kWrapped) {
+      for (int h = 0; h < 2; ++h) {
+        const v2f rx = v2f{pxs[2 * h], pxs[2 * h + 1]} - xi2;
+        const v2f ry = v2f{pys[2 * h], pys[2 * h + 1]} - yi2;
+        const v2f rz = v2f{pzs[2 * h], pzs[2 * h + 1]} - zi2;
         // |r| >= t_wrap = nextafter(L/2) selects L - |r| (same magnitude as the
         // literal |r| - L); below it L - |r| >= |r|, so the minimum is exact.
-        ax = fabsf(pxs[u] - xi);
-        ay = fabsf(pys[u] - yi);
-        az = fabsf(pzs[u] - zi);
-        ax = fminf(ax, p.box[0] - ax);
-        ay = fminf(ay, p.box[1] - ay);
-        az = fminf(az, p.box[2] - az);
-      } else {
-        ax = pxs[u] - xi;
-        ay = pys[u] - yi;
-        az = pzs[u] - zi;
+        v2f ax, ay, az;
+        ax.x = fminf(fabsf(rx.x), p.box[0] - fabsf(rx.x));
+        ax.y = fminf(fabsf(rx.y), p.box[0] - fabsf(rx.y));
+        ay.x = fminf(fabsf(ry.x), p.box[1] - fabsf(ry.x));
+        ay.y = fminf(fabsf(ry.y), p.box[1] - fabsf(ry.y));
+        az.x = fminf(fabsf(rz.x), p.box[2] - fabsf(rz.x));
+        az.y = fminf(fabsf(rz.y), p.box[2] - fabsf(rz.y));
+        const v2f s2 = (ax * ax + ay * ay) + az * az;
+        const v2f root = {__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
+        const v2f t2 = __builtin_elementwise_fma(root, inv_step2, eps2);
+        s[2 * h] = s2.x;
+        s[2 * h + 1] = s2.y;
+        b[2 * h] = static_cast<int>(t2.x);
+        b[2 * h + 1] = static_cast<int>(t2.y);
+        near_edge[2 * h] = __builtin_amdgcn_fractf(t2.x) < p.edge_eps2;
+        near_edge[2 * h + 1] = __builtin_amdgcn_fractf(t2.y) < p.edge_eps2;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        keep[u] = s[u] < p.s_cut;
+        if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float ax = pxs[u] - xi;
+        float ay = pys[u] - yi;
+        float az = pzs[u] - zi;
         ax = ax - exact_rint_quotient(ax, p.box[0], p.inv_box[0]) * p.box[0];
         ay = ay - exact_rint_quotient(ay, p.box[1], p.inv_box[1]) * p.box[1];
         az = az - exact_rint_quotient(az, p.box[2], p.inv_box[2]) * p.box[2];
+        s[u] = (ax * ax + ay * ay) + az * az;
+        keep[u] = s[u] < p.s_cut;
+        if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
+        // bin position shifted up by the error bound eps: away from an edge its
+        // integer part is the bin, and "within eps of an edge" is fract < 2 eps
+        const float t = __builtin_fmaf(__builtin_amdgcn_sqrtf(s[u]), p.inv_step, p.edge_eps);
+        b[u] = static_cast<int>(t);
+        near_edge[u] = __builtin_amdgcn_fractf(t) < p.edge_eps2;
       }
-      s[u] = (ax * ax + ay * ay) + az * az;
-      keep[u] = s[u] < p.s_cut;
-      if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
-      // bin position shifted up by the error bound eps: away from an edge its
-      // integer part is the bin, and "within eps of an edge" is fract < 2 eps
-      const float t = __builtin_fmaf(__builtin_amdgcn_sqrtf(s[u]), p.inv_step, p.edge_eps);
-      b[u] = static_cast<int>(t);
-      near_edge[u] = __builtin_amdgcn_fractf(t) < p.edge_eps2;
     }
     const bool fix = (keep[0] && near_edge[0]) || (keep[1] && near_edge[1]) ||
                      (keep[2] && near_edge[2]) || (keep[3] && near_edge[3]);
