@@ -12,12 +12,21 @@
 //   acf_finish_kernel    per window: c = scale/(R-m) * sum_chunks C, running sum of c
 //                        (the calculator's acf_array), trapezoid running integral by
 //                        a block scan, Welford mean / M2 of the integral over windows
+//   acf_slide_kernel     identity lags and a small correlation time: consecutive windows
+//                        overlap in all but 2*ct lag products, so a block computes its
+//                        first window directly and then slides, fused with the
+//                        per-window statistics of acf_finish_kernel
+//   acf_band_kernel      many series: Q[t][m] = sum_s sum_d x_s[t] x_s[t+m], the lag
+//                        products summed over series once, which acf_slide_kernel then
+//                        consumes instead of the series themselves
 //   msd_kernel           per block partial sums of squared displacements
 //   combine kernels      fixed-order sums of the per-block partials
 //
-// All accumulation is float64; float32 input is widened exactly.
+// All accumulation is float64 (fused multiply-add in the product loops); float32
+// input is widened exactly.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "mdx_common.h"
 
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void acf_partial_kernel(
           for (int n = 0; n < R - m1; ++n) {
             const double *a = base + n * k;
             const double *b = base + (n + m1) * k;
-            for (int d = 0; d < k; ++d) sum = sum + a[d] * b[d];
+            for (int d = 0; d < k; ++d) sum = fma(a[d], b[d], sum);
           }
           acc1[o] += sum;
           if (m2 != m1) {
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void acf_partial_kernel(
             for (int n = 0; n < R - m2; ++n) {
               const double *a = base + n * k;
               const double *b = base + (n + m2) * k;
-              for (int d = 0; d < k; ++d) sum = sum + a[d] * b[d];
+              for (int d = 0; d < k; ++d) sum = fma(a[d], b[d], sum);
             }
             acc2[o] += sum;
           }
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void acf_partial_kernel(
           for (int n = 0; n < R - m1; ++n) {
             const double *a = base + tau_l[n] * k;
             const double *b = base + tau_l[n + m1] * k;
-            for (int d = 0; d < k; ++d) sum = sum + a[d] * b[d];
+            for (int d = 0; d < k; ++d) sum = fma(a[d], b[d], sum);
           }
           acc1[o] += sum;
           if (m2 != m1) {
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(kThreads) void acf_partial_kernel(
             for (int n = 0; n < R - m2; ++n) {
               const double *a = base + tau_l[n] * k;
               const double *b = base + tau_l[n + m2] * k;
-              for (int d = 0; d < k; ++d) sum = sum + a[d] * b[d];
+              for (int d = 0; d < k; ++d) sum = fma(a[d], b[d], sum);
             }
             acc2[o] += sum;
           }
@@ -187,6 +196,228 @@ __global__ __launch_bounds__(kThreads) void acf_finish_kernel(
   }
 }
 
+// ------------------------------------------------------- ACF, sliding windows
+
+// Lag product P(t, m) = sum_s sum_d x_s[t][d] * x_s[t + m][d], from the series.
+template <typename T>
+struct SeriesProduct {
+  const T *x;
+  int64_t n_series, n_frames;
+  int k;
+  __device__ __forceinline__ double operator()(int64_t t, int m) const {
+    double sum = 0.0;
+    for (int64_t s = 0; s < n_series; ++s) {
+      const T *a = x + (s * n_frames + t) * k;
+      const T *b = a + static_cast<int64_t>(m) * k;
+      for (int d = 0; d < k; ++d)
+        sum = fma(static_cast<double>(a[d]), static_cast<double>(b[d]), sum);
+    }
+    return sum;
+  }
+};
+
+// The same product read from the band table of acf_band_kernel (frames t0 ..
+// t0 + t_len - 1), after its series-chunk planes have been summed.
+struct BandProduct {
+  const double *Q;
+  int64_t t0;
+  int R;
+  __device__ __forceinline__ double operator()(int64_t t, int m) const {
+    return Q[(t - t0) * R + m];
+  }
+};
+
+// Q[0][e] = sum_chunks Q[chunk][e], planes in index order.
+__global__ __launch_bounds__(kThreads) void band_combine_kernel(double *__restrict__ Q,
+                                                                int n_chunks, int64_t plane) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= plane) return;
+  double sum = Q[e];
+  for (int ch = 1; ch < n_chunks; ++ch) sum = sum + Q[static_cast<int64_t>(ch) * plane + e];
+  Q[e] = sum;
+}
+
+// One block walks over windows [w0, w1) of the launch.  W[m] = sum_{n < R - m}
+// P(o + n, m) for the window origin o is computed directly for the first window
+// and updated by the 2*ct products that leave and enter for every later one.
+// Outputs as acf_finish_kernel, at block index block_offset + blockIdx.x.
+template <typename Product>
+__global__ __launch_bounds__(kThreads) void acf_slide_kernel(
+    Product prod, int64_t ct, int64_t win_begin, int64_t n_win, int64_t windows_per_block,
+    int R, double scale, double integral_scale, const double *__restrict__ time,
+    int64_t block_offset, double *__restrict__ acf_blk, double *__restrict__ mean_blk,
+    double *__restrict__ m2_blk) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *Wl = reinterpret_cast<double *>(lds_raw);  // [R] unnormalised window sums
+  double *cs = Wl + R;                               // [R] window correlation
+  double *tot = cs + R;                              // [kThreads] segment totals
+  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * windows_per_block;
+  const int64_t w1 = min(n_win, w0 + windows_per_block);
+  const int64_t blk = block_offset + blockIdx.x;
+  double *acf = acf_blk + blk * R;
+  double *mean = mean_blk + blk * (R - 1);
+  double *m2 = m2_blk + blk * (R - 1);
+  const int n_int = R - 1;
+  const int seg = (n_int + kThreads - 1) / kThreads;
+  const int i0 = min(n_int, static_cast<int>(threadIdx.x) * seg);
+  const int i1 = min(n_int, i0 + seg);
+  for (int i = i0; i < i1; ++i) {
+    mean[i] = 0.0;
+    m2[i] = 0.0;
+  }
+  const int64_t o0 = (win_begin + w0) * ct;
+  for (int m = threadIdx.x; m < R; m += kThreads) {
+    acf[m] = 0.0;
+    double sum = 0.0;
+    for (int n = 0; n < R - m; ++n) sum = sum + prod(o0 + n, m);
+    Wl[m] = sum;
+  }
+  for (int64_t w = w0; w < w1; ++w) {
+    const int64_t o_prev = (win_begin + w - 1) * ct;
+    __syncthreads();  // the previous window's reads of cs are complete
+    for (int m = threadIdx.x; m < R; m += kThreads) {
+      double W = Wl[m];
+      if (w > w0) {
+        for (int64_t n = 0; n < ct; ++n)
+          W = W + (prod(o_prev + (R - m) + n, m) - prod(o_prev + n, m));
+        Wl[m] = W;
+      }
+      const double c = W * (scale / static_cast<double>(R - m));
+      acf[m] = acf[m] + c;
+      cs[m] = c * integral_scale;
+    }
+    if (time == nullptr) continue;  // uniform: no integral requested
+    __syncthreads();
+    double run = 0.0;
+    for (int i = i0; i < i1; ++i)
+      run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
+    tot[threadIdx.x] = run;
+    __syncthreads();
+    double offset = 0.0;
+    for (int t = 0; t < static_cast<int>(threadIdx.x); ++t) offset = offset + tot[t];
+    run = offset;
+    const double count = static_cast<double>(w - w0 + 1);
+    for (int i = i0; i < i1; ++i) {
+      run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
+      const double delta = run - mean[i];
+      const double mu = mean[i] + delta / count;
+      mean[i] = mu;
+      m2[i] = m2[i] + delta * (run - mu);
+    }
+  }
+}
+
+// Band table Q[chunk][t][m] = sum_{s in chunk} sum_d x_s[t0 + t][d] * x_s[t0 + t + m][d]
+// for t < t_len, m < R.  A block owns a tile of kBandT frames x kBandM lags and a
+// chunk of series; a thread owns an 8 x 8 patch of it, whose 64 products per
+// dimension need only 8 + 15 staged values because x_s[t + m] depends on t + m.
+// The frames of one series are staged per dimension with one pad slot after
+// every 8 frames, which spreads the 8-frame lane stride over all LDS banks.
+constexpr int kBandT = 64;
+constexpr int kBandM = 256;
+constexpr int kBandSpan = kBandT + kBandM;  // frames t + m a tile touches
+
+// K = number of components when known at compile time (the next series is then
+// fetched into registers while the current one is being multiplied), 0 otherwise.
+template <typename T, int K>
+__global__ __launch_bounds__(kThreads) void acf_band_kernel(
+    const T *__restrict__ x, int64_t n_series, int64_t n_frames, int k_runtime, int64_t t0,
+    int64_t t_len, int R, int64_t series_per_chunk, double *__restrict__ Q) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *img = reinterpret_cast<double *>(lds_raw);  // [2][k][pitch]
+  const int k = (K > 0) ? K : k_runtime;
+  const int mg = threadIdx.x & 31;
+  const int tg = threadIdx.x >> 5;
+  const int64_t tile_t = static_cast<int64_t>(blockIdx.x) * kBandT;
+  const int tile_m = blockIdx.y * kBandM;
+  const int64_t s0 = static_cast<int64_t>(blockIdx.z) * series_per_chunk;
+  const int64_t s1 = min(n_series, s0 + series_per_chunk);
+  // staged per series: the tile's kBandT frames x[t] first, then the kBandSpan
+  // frames x[t + m] starting at frame0
+  const int64_t frame0 = t0 + tile_t + tile_m;
+  constexpr int n_stage = kBandT + kBandSpan;
+  constexpr int pitch = n_stage + n_stage / 8;
+  constexpr int kOwn = (n_stage + kThreads - 1) / kThreads;  // frames a thread stages
+  const int plane = k * pitch;
+
+  // the frames this thread stages (the same for every series)
+  int64_t own_frame[kOwn];
+  int own_slot[kOwn];
+#pragma unroll
+  for (int o = 0; o < kOwn; ++o) {
+    const int f = threadIdx.x + o * kThreads;
+    const int64_t frame = (f < kBandT) ? (t0 + tile_t + f) : (frame0 + (f - kBandT));
+    own_frame[o] = (f < n_stage && frame < n_frames) ? frame : -1;
+    own_slot[o] = (f < n_stage) ? f + (f >> 3) : -1;
+  }
+
+  double acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+
+  T pre[kOwn][K > 0 ? K : 1];
+  auto fetch = [&](int64_t s) {
+    const T *series = x + s * n_frames * k;
+#pragma unroll
+    for (int o = 0; o < kOwn; ++o)
+#pragma unroll
+      for (int d = 0; d < K; ++d)
+        pre[o][d] = (own_frame[o] >= 0) ? series[own_frame[o] * K + d] : T(0);
+  };
+  if (K > 0 && s0 < s1) fetch(s0);
+
+  int buf = 0;
+  for (int64_t s = s0; s < s1; ++s) {
+    double *dst = img + static_cast<size_t>(buf) * plane;
+    if (K > 0) {
+#pragma unroll
+      for (int o = 0; o < kOwn; ++o)
+        if (own_slot[o] >= 0) {
+#pragma unroll
+          for (int d = 0; d < K; ++d) dst[d * pitch + own_slot[o]] = static_cast<double>(pre[o][d]);
+        }
+    } else {
+      const T *series = x + s * n_frames * k;
+#pragma unroll
+      for (int o = 0; o < kOwn; ++o)
+        if (own_slot[o] >= 0) {
+          for (int d = 0; d < k; ++d)
+            dst[d * pitch + own_slot[o]] =
+                (own_frame[o] >= 0) ? static_cast<double>(series[own_frame[o] * k + d]) : 0.0;
+        }
+    }
+    __syncthreads();
+    if (K > 0 && s + 1 < s1) fetch(s + 1);
+    for (int d = 0; d < k; ++d) {
+      const double *row = dst + d * pitch;
+      double a[8], b[15];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = row[9 * tg + i];
+      const double *rb = row + (kBandT + kBandT / 8) + 9 * (tg + mg);
+#pragma unroll
+      for (int c = 0; c < 15; ++c) b[c] = rb[c + (c >> 3)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = fma(a[i], b[i + j], acc[i][j]);
+    }
+    buf ^= 1;  // the other image was last read before this iteration's barrier
+  }
+  double *out = Q + static_cast<int64_t>(blockIdx.z) * t_len * R;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t t = tile_t + 8 * tg + i;
+    if (t >= t_len) continue;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = tile_m + 8 * mg + j;
+      if (m < R) out[t * R + m] = acc[i][j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------ MSD
 
 // partial[block][i] = sum over the block's windows and series of
@@ -219,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void msd_kernel(
         const double *later = origin + static_cast<size_t>(t) * k;
         for (int d = 0; d < k; ++d) {
           const double diff = later[d] - origin[d];
-          sum = sum + diff * diff;
+          sum = fma(diff, diff, sum);
         }
       }
       out[i] = out[i] + sum;
@@ -325,76 +556,205 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
     MDX_HIP(hipMemcpyAsync(d_time.ptr, time, sizeof(double) * R, hipMemcpyHostToDevice, stream));
   }
 
-  // stage A geometry
-  const int n_pairs = (R + 1) / 2;
-  int cap = (kMaxOwned * kThreads) / n_pairs;
-  if (cap < 1) cap = 1;
-  if (cap > 8) cap = 8;
-  const int wpb = windows_per_block(correlation_time, ti.D, k, n_win, cap, 96 * 1024);
-  const size_t lds_a =
-      static_cast<size_t>((wpb - 1) * correlation_time + ti.D) * k * sizeof(double) +
-      sizeof(int32_t) * R + 16;
-  MDX_REQUIRE(lds_a <= 160 * 1024 - 512,
-              "data_range %d with %d dims needs %zu bytes of LDS, more than a gfx950 "
-              "compute unit has",
-              ti.D, k, lds_a);
-  MDX_REQUIRE(static_cast<int64_t>(wpb) * n_pairs <= kMaxOwned * kThreads,
-              "n_tau too large for the direct kernel");
-  const int64_t win_blocks = ceil_div(n_win, wpb);
-  // series chunks: enough blocks to fill the chip, bounded partial-sum memory
-  int64_t n_chunks = ceil_div(2048, win_blocks);
-  if (n_chunks > n_series) n_chunks = n_series;
-  if (n_chunks > 64) n_chunks = 64;
-  const size_t c_bytes_one = sizeof(double) * static_cast<size_t>(n_win) * R;
-  while (n_chunks > 1 && c_bytes_one * n_chunks > (size_t(8) << 30)) --n_chunks;
-  const int64_t series_per_chunk = ceil_div(n_series, n_chunks);
-  n_chunks = ceil_div(n_series, series_per_chunk);
-  MDX_REQUIRE(win_blocks <= 2147483647LL && n_chunks <= 65535, "grid too large");
-  MDX_TRY(d_C.alloc(c_bytes_one * n_chunks));
-
-  dim3 grid_a(static_cast<unsigned>(win_blocks), static_cast<unsigned>(n_chunks));
-#define MDX_LAUNCH_ACF(TYPE, KK)                                                          \
-  do {                                                                                    \
-    MDX_HIP(hipFuncSetAttribute(                                                          \
-        reinterpret_cast<const void *>(acf_partial_kernel<TYPE, KK>),                     \
-        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_a)));            \
-    hipLaunchKernelGGL((acf_partial_kernel<TYPE, KK>), grid_a, dim3(kThreads), lds_a,     \
-                       stream, static_cast<const TYPE *>(dx), n_series, n_frames, k,      \
-                       correlation_time, win_begin, n_win, wpb, d_tau.as<int32_t>(), R,   \
-                       ti.D, ti.identity ? 1 : 0, series_per_chunk, d_C.as<double>());    \
-  } while (0)
-  {
-    KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
-    if (dtype == MDX_F32) {
-      if (k == 3) MDX_LAUNCH_ACF(float, 3); else MDX_LAUNCH_ACF(float, 0);
-    } else {
-      if (k == 3) MDX_LAUNCH_ACF(double, 3); else MDX_LAUNCH_ACF(double, 0);
-    }
-  }
-#undef MDX_LAUNCH_ACF
-  MDX_HIP(hipGetLastError());
-
-  // stage B geometry: contiguous window ranges per block
-  int64_t n_blocks_b = n_win < 1024 ? n_win : 1024;
-  const int64_t wins_per_block_b = ceil_div(n_win, n_blocks_b);
-  n_blocks_b = ceil_div(n_win, wins_per_block_b);
+  // per-block results of whichever path runs; block_windows[b] = windows of block b
+  std::vector<int64_t> block_windows;
   const int n_int = R > 1 ? R - 1 : 1;
-  MDX_TRY(d_acf.alloc(sizeof(double) * n_blocks_b * R));
-  MDX_TRY(d_mean.alloc(sizeof(double) * n_blocks_b * n_int));
-  MDX_TRY(d_m2.alloc(sizeof(double) * n_blocks_b * n_int));
-  const size_t lds_b = sizeof(double) * (static_cast<size_t>(R) + kThreads);
-  MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_finish_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds_b)));
-  {
-    KernelTimer timer(MDX_SLOT_ACF_FINISH, stream);
-    hipLaunchKernelGGL(acf_finish_kernel, dim3(static_cast<unsigned>(n_blocks_b)),
-                       dim3(kThreads), lds_b, stream, d_C.as<double>(),
-                       static_cast<int>(n_chunks), n_win, wins_per_block_b, R, scale,
-                       integral_scale, want_integral ? d_time.as<double>() : nullptr,
-                       d_acf.as<double>(), d_mean.as<double>(), d_m2.as<double>());
+  const bool slide = ti.identity && R >= 2 && 4 * correlation_time <= R;
+  if (slide) {
+    const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + kThreads);
+    const bool band = n_series > 8;
+    // windows per block: enough to amortise the directly computed first window
+    // (R/2 products per lag against 2*ct per slide), few enough to fill the chip
+    // and to bound the drift of the running sums
+    auto plan_wpb = [&](int64_t windows) {
+      int64_t amortise = R / (4 * correlation_time);
+      const int64_t spread = ceil_div(windows, 256);
+      if (amortise > spread) amortise = spread;
+      int64_t wpb = ceil_div(windows, 2048);
+      if (wpb < amortise) wpb = amortise;
+      if (wpb > 512) wpb = 512;
+      if (wpb < 1) wpb = 1;
+      return wpb;
+    };
+    // window segments: the whole range at once from the series, or as many windows
+    // as a 2 GiB band table covers
+    int64_t seg_windows = n_win;
+    int64_t n_chunks = 1, series_per_chunk = n_series;
+    if (band) {
+      // series chunks only as far as needed to fill the chip with band tiles
+      const int64_t tiles = ceil_div((n_win - 1) * correlation_time + R, kBandT) *
+                            ceil_div(R, kBandM);
+      n_chunks = ceil_div(2048, tiles);
+      if (n_chunks > n_series / 32) n_chunks = n_series / 32;
+      if (n_chunks > 16) n_chunks = 16;
+      if (n_chunks < 1) n_chunks = 1;
+      series_per_chunk = ceil_div(n_series, n_chunks);
+      n_chunks = ceil_div(n_series, series_per_chunk);
+      // table budget: 2 GiB unless MDX_ACF_BAND_TABLE_BYTES says otherwise
+      size_t budget = size_t(2) << 30;
+      if (const char *env = getenv("MDX_ACF_BAND_TABLE_BYTES")) {
+        const long long v = atoll(env);
+        if (v > 0) budget = static_cast<size_t>(v);
+      }
+      const int64_t max_frames =
+          static_cast<int64_t>(budget / (sizeof(double) * R * n_chunks));
+      MDX_REQUIRE(max_frames > R, "data_range %d is too large for the band table", R);
+      seg_windows = (max_frames - R) / correlation_time + 1;
+      if (seg_windows > n_win) seg_windows = n_win;
+    }
+    int64_t total_blocks = 0;
+    for (int64_t ws = 0; ws < n_win; ws += seg_windows) {
+      const int64_t nw = std::min(seg_windows, n_win - ws);
+      total_blocks += ceil_div(nw, plan_wpb(nw));
+    }
+    MDX_TRY(d_acf.alloc(sizeof(double) * total_blocks * R));
+    MDX_TRY(d_mean.alloc(sizeof(double) * total_blocks * n_int));
+    MDX_TRY(d_m2.alloc(sizeof(double) * total_blocks * n_int));
+    const int64_t seg_frames = (seg_windows - 1) * correlation_time + R;
+    if (band) MDX_TRY(d_C.alloc(sizeof(double) * n_chunks * seg_frames * R));
+    const double *d_time_ptr = want_integral ? d_time.as<double>() : nullptr;
+
+    int64_t block_offset = 0;
+    for (int64_t ws = 0; ws < n_win; ws += seg_windows) {
+      const int64_t nw = std::min(seg_windows, n_win - ws);
+      const int64_t wpb = plan_wpb(nw);
+      const int64_t n_blocks = ceil_div(nw, wpb);
+      for (int64_t b = 0; b < n_blocks; ++b)
+        block_windows.push_back(std::min(wpb, nw - b * wpb));
+      const int64_t t0 = (win_begin + ws) * correlation_time;
+      const int64_t t_len = (nw - 1) * correlation_time + R;
+      if (band) {
+        const size_t lds_q = sizeof(double) * 2 * k *
+                             static_cast<size_t>((kBandT + kBandSpan) + (kBandT + kBandSpan) / 8);
+        dim3 grid_q(static_cast<unsigned>(ceil_div(t_len, kBandT)),
+                    static_cast<unsigned>(ceil_div(R, kBandM)), static_cast<unsigned>(n_chunks));
+        KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
+#define MDX_LAUNCH_BAND(TYPE, KK)                                                            \
+  do {                                                                                       \
+    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_band_kernel<TYPE, KK>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                static_cast<int>(lds_q)));                                   \
+    hipLaunchKernelGGL((acf_band_kernel<TYPE, KK>), grid_q, dim3(kThreads), lds_q, stream,   \
+                       static_cast<const TYPE *>(dx), n_series, n_frames, k, t0, t_len, R,   \
+                       series_per_chunk, d_C.as<double>());                                  \
+  } while (0)
+        if (dtype == MDX_F32) {
+          if (k == 3) MDX_LAUNCH_BAND(float, 3); else MDX_LAUNCH_BAND(float, 0);
+        } else {
+          if (k == 3) MDX_LAUNCH_BAND(double, 3); else MDX_LAUNCH_BAND(double, 0);
+        }
+#undef MDX_LAUNCH_BAND
+        MDX_HIP(hipGetLastError());
+        if (n_chunks > 1) {
+          const int64_t plane = t_len * R;
+          hipLaunchKernelGGL(band_combine_kernel,
+                             dim3(static_cast<unsigned>(ceil_div(plane, kThreads))),
+                             dim3(kThreads), 0, stream, d_C.as<double>(),
+                             static_cast<int>(n_chunks), plane);
+          MDX_HIP(hipGetLastError());
+        }
+      }
+      KernelTimer timer(MDX_SLOT_ACF_FINISH, stream);
+#define MDX_LAUNCH_SLIDE(PRODUCT_TYPE, PRODUCT)                                              \
+  do {                                                                                       \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(acf_slide_kernel<PRODUCT_TYPE>),                      \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_s)));               \
+    hipLaunchKernelGGL(acf_slide_kernel<PRODUCT_TYPE>, dim3(static_cast<unsigned>(n_blocks)), \
+                       dim3(kThreads), lds_s, stream, PRODUCT, correlation_time,             \
+                       win_begin + ws, nw, wpb, R, scale, integral_scale, d_time_ptr,        \
+                       block_offset, d_acf.as<double>(), d_mean.as<double>(),                \
+                       d_m2.as<double>());                                                   \
+  } while (0)
+      if (band) {
+        BandProduct prod{d_C.as<double>(), t0, R};
+        MDX_LAUNCH_SLIDE(BandProduct, prod);
+      } else if (dtype == MDX_F32) {
+        SeriesProduct<float> prod{static_cast<const float *>(dx), n_series, n_frames, k};
+        MDX_LAUNCH_SLIDE(SeriesProduct<float>, prod);
+      } else {
+        SeriesProduct<double> prod{static_cast<const double *>(dx), n_series, n_frames, k};
+        MDX_LAUNCH_SLIDE(SeriesProduct<double>, prod);
+      }
+#undef MDX_LAUNCH_SLIDE
+      MDX_HIP(hipGetLastError());
+      block_offset += n_blocks;
+    }
+  } else {
+    // stage A geometry
+    const int n_pairs = (R + 1) / 2;
+    int cap = (kMaxOwned * kThreads) / n_pairs;
+    if (cap < 1) cap = 1;
+    if (cap > 8) cap = 8;
+    const int wpb = windows_per_block(correlation_time, ti.D, k, n_win, cap, 96 * 1024);
+    const size_t lds_a =
+        static_cast<size_t>((wpb - 1) * correlation_time + ti.D) * k * sizeof(double) +
+        sizeof(int32_t) * R + 16;
+    MDX_REQUIRE(lds_a <= 160 * 1024 - 512,
+                "data_range %d with %d dims needs %zu bytes of LDS, more than a gfx950 "
+                "compute unit has",
+                ti.D, k, lds_a);
+    MDX_REQUIRE(static_cast<int64_t>(wpb) * n_pairs <= kMaxOwned * kThreads,
+                "n_tau too large for the direct kernel");
+    const int64_t win_blocks = ceil_div(n_win, wpb);
+    // series chunks: enough blocks to fill the chip, bounded partial-sum memory
+    int64_t n_chunks = ceil_div(2048, win_blocks);
+    if (n_chunks > n_series) n_chunks = n_series;
+    if (n_chunks > 64) n_chunks = 64;
+    const size_t c_bytes_one = sizeof(double) * static_cast<size_t>(n_win) * R;
+    while (n_chunks > 1 && c_bytes_one * n_chunks > (size_t(8) << 30)) --n_chunks;
+    const int64_t series_per_chunk = ceil_div(n_series, n_chunks);
+    n_chunks = ceil_div(n_series, series_per_chunk);
+    MDX_REQUIRE(win_blocks <= 2147483647LL && n_chunks <= 65535, "grid too large");
+    MDX_TRY(d_C.alloc(c_bytes_one * n_chunks));
+
+    dim3 grid_a(static_cast<unsigned>(win_blocks), static_cast<unsigned>(n_chunks));
+#define MDX_LAUNCH_ACF(TYPE, KK)                                                          \
+    do {                                                                                    \
+      MDX_HIP(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void *>(acf_partial_kernel<TYPE, KK>),                     \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_a)));            \
+      hipLaunchKernelGGL((acf_partial_kernel<TYPE, KK>), grid_a, dim3(kThreads), lds_a,     \
+                         stream, static_cast<const TYPE *>(dx), n_series, n_frames, k,      \
+                         correlation_time, win_begin, n_win, wpb, d_tau.as<int32_t>(), R,   \
+                         ti.D, ti.identity ? 1 : 0, series_per_chunk, d_C.as<double>());    \
+    } while (0)
+    {
+      KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
+      if (dtype == MDX_F32) {
+        if (k == 3) MDX_LAUNCH_ACF(float, 3); else MDX_LAUNCH_ACF(float, 0);
+      } else {
+        if (k == 3) MDX_LAUNCH_ACF(double, 3); else MDX_LAUNCH_ACF(double, 0);
+      }
+    }
+#undef MDX_LAUNCH_ACF
+    MDX_HIP(hipGetLastError());
+
+    // stage B geometry: contiguous window ranges per block
+    int64_t n_blocks_b = n_win < 1024 ? n_win : 1024;
+    const int64_t wins_per_block_b = ceil_div(n_win, n_blocks_b);
+    n_blocks_b = ceil_div(n_win, wins_per_block_b);
+    MDX_TRY(d_acf.alloc(sizeof(double) * n_blocks_b * R));
+    MDX_TRY(d_mean.alloc(sizeof(double) * n_blocks_b * n_int));
+    MDX_TRY(d_m2.alloc(sizeof(double) * n_blocks_b * n_int));
+    const size_t lds_b = sizeof(double) * (static_cast<size_t>(R) + kThreads);
+    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_finish_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_b)));
+    {
+      KernelTimer timer(MDX_SLOT_ACF_FINISH, stream);
+      hipLaunchKernelGGL(acf_finish_kernel, dim3(static_cast<unsigned>(n_blocks_b)),
+                         dim3(kThreads), lds_b, stream, d_C.as<double>(),
+                         static_cast<int>(n_chunks), n_win, wins_per_block_b, R, scale,
+                         integral_scale, want_integral ? d_time.as<double>() : nullptr,
+                         d_acf.as<double>(), d_mean.as<double>(), d_m2.as<double>());
+    }
+    MDX_HIP(hipGetLastError());
+
+    for (int64_t b = 0; b < n_blocks_b; ++b)
+      block_windows.push_back(std::min(wins_per_block_b, n_win - b * wins_per_block_b));
   }
-  MDX_HIP(hipGetLastError());
+  const int64_t n_blocks_b = static_cast<int64_t>(block_windows.size());
 
   std::vector<double> h_acf(static_cast<size_t>(n_blocks_b) * R);
   std::vector<double> h_mean, h_m2;
@@ -417,9 +777,7 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
     for (int i = 0; i < R - 1; ++i) {
       double n_a = 0.0, mean_a = 0.0, m2_a = 0.0;
       for (int64_t b = 0; b < n_blocks_b; ++b) {
-        const int64_t wb0 = b * wins_per_block_b;
-        const int64_t wb1 = std::min(n_win, wb0 + wins_per_block_b);
-        const double n_b = static_cast<double>(wb1 - wb0);
+        const double n_b = static_cast<double>(block_windows[b]);
         if (n_b <= 0.0) continue;
         const double mean_b = h_mean[b * (R - 1) + i];
         const double m2_b = h_m2[b * (R - 1) + i];

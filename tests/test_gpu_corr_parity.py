@@ -133,6 +133,61 @@ def test_acf_subsampled_tau(gpu):
     assert_close(acf, ref)
 
 
+def test_acf_direct_kernel_for_large_correlation_time(gpu):
+    """Windows further apart than a quarter of their length share too few lag
+    products to slide; they are evaluated one by one."""
+    rng = np.random.default_rng(15)
+    x = rng.normal(size=(3, 900, 3))
+    tau = np.arange(64)
+    time = tau * 0.5
+    n_win = (900 - 64) // 20
+    acf, mom = gpu.acf_windows(x, 20, 0, n_win, tau, scale=0.3, time=time)
+    ref_pw = 0.3 * _per_window_reference(x, 20, 0, n_win, tau)
+    assert_close(acf, ref_pw.sum(axis=0))
+    sig = np.array([cumulative_trapezoid(r, x=time) for r in ref_pw])
+    assert_close(mom.mean, sig.mean(axis=0))
+    assert_close(mom.std(), np.std(sig, axis=0))
+
+
+@pytest.mark.parametrize("S,T,D,k,ct,table_bytes", [
+    (40, 1500, 300, 3, 1, None),        # two lag tiles, ragged edges
+    (70, 900, 100, 1, 3, None),         # scalar series, two series chunks
+    (24, 700, 65, 6, 2, None),          # six components (stress-like)
+    (33, 1200, 128, 3, 1, 600_000),     # band table rebuilt for several window segments
+])
+def test_acf_many_series_band_table(gpu, monkeypatch, S, T, D, k, ct, table_bytes):
+    """More than a handful of series: lag products are summed over series into a
+    band table first, windows slide over that table."""
+    if table_bytes is not None:
+        monkeypatch.setenv("MDX_ACF_BAND_TABLE_BYTES", str(table_bytes))
+    rng = np.random.default_rng(16)
+    v = (rng.normal(size=(S, T, k)) + 0.3).astype(np.float32)
+    tau = np.arange(D)
+    time = tau * 0.01
+    n_win = int(np.clip((T - D) / ct, 1, None))
+    acf, mom = gpu.acf_windows(v, ct, 0, n_win, tau, scale=2.0, integral_scale=0.5, time=time)
+    v64 = v.astype(np.float64)
+    assert_close(acf, c_oracle.acf_windows(v64, ct, 0, n_win, tau, scale=2.0))
+    ref_pw = 2.0 * _per_window_reference(v64, ct, 0, n_win, tau)
+    assert_close(acf, ref_pw.sum(axis=0))
+    sig = np.array([cumulative_trapezoid(0.5 * r, x=time) for r in ref_pw])
+    assert mom.n == n_win
+    assert_close(mom.mean, sig.mean(axis=0))
+    assert_close(mom.std(), np.std(sig, axis=0))
+
+
+def test_acf_sliding_sums_do_not_drift(gpu):
+    """A long series with a large offset: the running window sums are restarted
+    often enough that cancellation stays far below the tolerance."""
+    rng = np.random.default_rng(17)
+    T, D = 60_000, 200
+    x = (rng.normal(size=(1, T, 3)) + 25.0).astype(np.float32)
+    tau = np.arange(D)
+    n_win = T - D
+    acf, _ = gpu.acf_windows(x, 1, 0, n_win, tau)
+    assert_close(acf, c_oracle.acf_windows(x.astype(np.float64), 1, 0, n_win, tau), rtol=1e-10)
+
+
 def test_acf_rejects_windows_beyond_the_batch(gpu):
     x = np.zeros((1, 100, 3))
     with pytest.raises(ValueError):
