@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -44,9 +47,20 @@ int get_stream(hipStream_t *stream);
   } while (0)
 
 // Device allocation freed when it leaves scope (after the caller synchronised).
+// Device memory for the library's own buffers comes from a per-device cache of
+// freed blocks: every kernel and copy of the library runs on one stream per
+// device, so a block released in program order can be handed out again at once,
+// and repeated calls stop paying for hipMalloc / hipFree (which synchronise the
+// device).  pool_trim returns the cached blocks of every device to the driver.
+int pool_acquire(void **ptr, size_t bytes, size_t *capacity, int *device);
+void pool_release(void *ptr, size_t capacity, int device);
+void pool_trim();
+
 struct DeviceBuffer {
   void *ptr = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;     // requested size
+  size_t capacity = 0;  // size of the underlying block
+  int device = -1;
   DeviceBuffer() = default;
   DeviceBuffer(const DeviceBuffer &) = delete;
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
@@ -54,24 +68,27 @@ struct DeviceBuffer {
   int alloc(size_t n) {
     release();
     if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&ptr, n);
-    if (e != hipSuccess) {
+    const int rc = pool_acquire(&ptr, n, &capacity, &device);
+    if (rc != MDX_OK) {
       ptr = nullptr;
-      return fail(e == hipErrorOutOfMemory ? MDX_ERR_OUT_OF_MEMORY : MDX_ERR_DEVICE,
-                  "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+      return rc;
     }
     bytes = n;
     return MDX_OK;
   }
   // Grow-only reuse: keeps the allocation when it is already large enough.
   int reserve(size_t n) {
-    if (ptr != nullptr && bytes >= n) return MDX_OK;
+    if (ptr != nullptr && capacity >= n) {
+      if (bytes < n) bytes = n;
+      return MDX_OK;
+    }
     return alloc(n);
   }
   void release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr) pool_release(ptr, capacity, device);
     ptr = nullptr;
     bytes = 0;
+    capacity = 0;
   }
   template <typename T>
   T *as() const {

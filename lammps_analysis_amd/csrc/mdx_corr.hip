@@ -196,6 +196,36 @@ __global__ __launch_bounds__(kThreads) void acf_finish_kernel(
   }
 }
 
+// Merges the per-block results of acf_finish_kernel / acf_slide_kernel in block
+// order: out[0..R) = sum of the blocks' acf, out[R..2R-1) and out[2R-1..3R-2) = mean
+// and M2 of the running integral over all windows (pairwise update of Chan et al.).
+// Thread = lag / integral index.
+__global__ __launch_bounds__(64) void acf_merge_kernel(
+    const double *__restrict__ acf_blk, const double *__restrict__ mean_blk,
+    const double *__restrict__ m2_blk, const int64_t *__restrict__ counts, int64_t n_blocks,
+    int R, double *__restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= R) return;
+  double total = 0.0;
+  for (int64_t b = 0; b < n_blocks; ++b) total = total + acf_blk[b * R + i];
+  out[i] = total;
+  if (mean_blk == nullptr || i >= R - 1) return;
+  double n_a = 0.0, mean_a = 0.0, m2_a = 0.0;
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    const double n_b = static_cast<double>(counts[b]);
+    if (n_b <= 0.0) continue;
+    const double mean_b = mean_blk[b * (R - 1) + i];
+    const double m2_b = m2_blk[b * (R - 1) + i];
+    const double delta = mean_b - mean_a;
+    const double n_ab = n_a + n_b;
+    mean_a = mean_a + delta * (n_b / n_ab);
+    m2_a = m2_a + m2_b + delta * delta * (n_a * n_b / n_ab);
+    n_a = n_ab;
+  }
+  out[R + i] = mean_a;
+  out[R + (R - 1) + i] = m2_a;
+}
+
 // ------------------------------------------------------- ACF, sliding windows
 
 // Lag product P(t, m) = sum_s sum_d x_s[t][d] * x_s[t + m][d], from the series.
@@ -756,39 +786,28 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
   }
   const int64_t n_blocks_b = static_cast<int64_t>(block_windows.size());
 
-  std::vector<double> h_acf(static_cast<size_t>(n_blocks_b) * R);
-  std::vector<double> h_mean, h_m2;
-  MDX_HIP(hipMemcpyAsync(h_acf.data(), d_acf.ptr, sizeof(double) * h_acf.size(),
+  // merge the per-block results on the device: out = [acf R | mean R-1 | M2 R-1]
+  DeviceBuffer d_counts, d_out;
+  MDX_TRY(d_counts.alloc(sizeof(int64_t) * n_blocks_b));
+  MDX_HIP(hipMemcpyAsync(d_counts.ptr, block_windows.data(), sizeof(int64_t) * n_blocks_b,
+                         hipMemcpyHostToDevice, stream));
+  const bool merge_moments = want_integral && R > 1;
+  MDX_TRY(d_out.alloc(sizeof(double) * (static_cast<size_t>(R) + 2 * n_int)));
+  hipLaunchKernelGGL(acf_merge_kernel, dim3(static_cast<unsigned>(ceil_div(R, 64))), dim3(64),
+                     0, stream, d_acf.as<double>(),
+                     merge_moments ? d_mean.as<double>() : nullptr,
+                     merge_moments ? d_m2.as<double>() : nullptr, d_counts.as<int64_t>(),
+                     n_blocks_b, R, d_out.as<double>());
+  MDX_HIP(hipGetLastError());
+  std::vector<double> h_out(static_cast<size_t>(R) + 2 * n_int);
+  MDX_HIP(hipMemcpyAsync(h_out.data(), d_out.ptr, sizeof(double) * h_out.size(),
                          hipMemcpyDeviceToHost, stream));
-  if (want_integral && R > 1) {
-    h_mean.resize(static_cast<size_t>(n_blocks_b) * (R - 1));
-    h_m2.resize(h_mean.size());
-    MDX_HIP(hipMemcpyAsync(h_mean.data(), d_mean.ptr, sizeof(double) * h_mean.size(),
-                           hipMemcpyDeviceToHost, stream));
-    MDX_HIP(hipMemcpyAsync(h_m2.data(), d_m2.ptr, sizeof(double) * h_m2.size(),
-                           hipMemcpyDeviceToHost, stream));
-  }
   MDX_HIP(hipStreamSynchronize(stream));
-
-  for (int64_t b = 0; b < n_blocks_b; ++b)
-    for (int m = 0; m < R; ++m) acf_sum[m] += h_acf[b * R + m];
-  if (want_integral && R > 1) {
-    // merge the per-block (count, mean, M2) triples in block order
+  for (int m = 0; m < R; ++m) acf_sum[m] += h_out[m];
+  if (merge_moments) {
     for (int i = 0; i < R - 1; ++i) {
-      double n_a = 0.0, mean_a = 0.0, m2_a = 0.0;
-      for (int64_t b = 0; b < n_blocks_b; ++b) {
-        const double n_b = static_cast<double>(block_windows[b]);
-        if (n_b <= 0.0) continue;
-        const double mean_b = h_mean[b * (R - 1) + i];
-        const double m2_b = h_m2[b * (R - 1) + i];
-        const double delta = mean_b - mean_a;
-        const double n_ab = n_a + n_b;
-        mean_a = mean_a + delta * (n_b / n_ab);
-        m2_a = m2_a + m2_b + delta * delta * (n_a * n_b / n_ab);
-        n_a = n_ab;
-      }
-      integral_mean[i] = mean_a;
-      integral_m2[i] = m2_a;
+      integral_mean[i] = h_out[R + i];
+      integral_m2[i] = h_out[R + (R - 1) + i];
     }
   }
   return MDX_OK;

@@ -31,6 +31,95 @@ int get_stream(hipStream_t *stream) {
   return MDX_OK;
 }
 
+// ---- device memory cache
+namespace {
+struct DevicePool {
+  std::multimap<size_t, void *> free_blocks;  // capacity -> block
+  size_t cached_bytes = 0;
+};
+std::mutex g_pool_mutex;
+DevicePool g_pools[kMaxDevices];
+constexpr size_t kPoolCachedLimit = size_t(8) << 30;  // per device
+constexpr size_t kPoolBlockLimit = size_t(2) << 30;   // larger blocks are not cached
+
+void trim_device_locked(int dev) {
+  DevicePool &pool = g_pools[dev];
+  if (pool.free_blocks.empty()) return;
+  int current = 0;
+  const bool switched = hipGetDevice(&current) == hipSuccess && current != dev &&
+                        hipSetDevice(dev) == hipSuccess;
+  for (auto &entry : pool.free_blocks) (void)hipFree(entry.second);
+  pool.free_blocks.clear();
+  pool.cached_bytes = 0;
+  if (switched) (void)hipSetDevice(current);
+}
+}  // namespace
+
+int pool_acquire(void **ptr, size_t bytes, size_t *capacity, int *device) {
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices)
+    return fail(MDX_ERR_DEVICE, "device index %d out of range", dev);
+  // round up so that nearby sizes share blocks: 4 KiB granules up to 1 MiB, 1/8 of
+  // the leading power of two above
+  size_t want = (bytes + 4095) & ~size_t(4095);
+  if (want > (size_t(1) << 20)) {
+    size_t granule = size_t(1) << 17;
+    while (granule * 16 < want) granule <<= 1;
+    want = (want + granule - 1) / granule * granule;
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DevicePool &pool = g_pools[dev];
+    auto it = pool.free_blocks.lower_bound(want);
+    if (it != pool.free_blocks.end() && it->first <= want + want / 4) {
+      *ptr = it->second;
+      *capacity = it->first;
+      *device = dev;
+      pool.cached_bytes -= it->first;
+      pool.free_blocks.erase(it);
+      return MDX_OK;
+    }
+  }
+  hipError_t e = hipMalloc(ptr, want);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lock(g_pool_mutex);
+      trim_device_locked(dev);
+    }
+    e = hipMalloc(ptr, want);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *ptr = nullptr;
+    return fail(e == hipErrorOutOfMemory ? MDX_ERR_OUT_OF_MEMORY : MDX_ERR_DEVICE,
+                "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+  }
+  *capacity = want;
+  *device = dev;
+  return MDX_OK;
+}
+
+void pool_release(void *ptr, size_t capacity, int device) {
+  if (ptr == nullptr) return;
+  if (device >= 0 && device < kMaxDevices && capacity <= kPoolBlockLimit) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DevicePool &pool = g_pools[device];
+    if (pool.cached_bytes + capacity <= kPoolCachedLimit) {
+      pool.free_blocks.emplace(capacity, ptr);
+      pool.cached_bytes += capacity;
+      return;
+    }
+  }
+  (void)hipFree(ptr);
+}
+
+void pool_trim() {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  for (int dev = 0; dev < kMaxDevices; ++dev) trim_device_locked(dev);
+}
+
 int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
               hipStream_t stream, const void **dptr) {
   if (src == nullptr) return fail(MDX_ERR_INVALID_ARGUMENT, "null data pointer");
@@ -173,6 +262,11 @@ int mdx_malloc(void **dptr, size_t bytes) {
 int mdx_free(void *dptr) {
   if (dptr == nullptr) return MDX_OK;
   MDX_HIP(hipFree(dptr));
+  return MDX_OK;
+}
+
+int mdx_release_cached_memory(void) {
+  pool_trim();
   return MDX_OK;
 }
 

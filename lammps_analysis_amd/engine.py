@@ -27,6 +27,11 @@ def synchronize() -> None:
     check(_lib.load().mdx_synchronize())
 
 
+def release_cached_memory() -> None:
+    """Return the scratch blocks the library keeps cached between calls to the driver."""
+    check(_lib.load().mdx_release_cached_memory())
+
+
 def device_info() -> dict:
     name = ctypes.create_string_buffer(256)
     cus = ctypes.c_int(0)
