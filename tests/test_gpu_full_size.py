@@ -1,0 +1,88 @@
+"""GPU checks at the sizes the benchmark configurations name.
+
+Where the CPU oracle finishes in seconds the comparison stays direct (one frame of
+the 100k-atom water box); beyond that the results are checked through properties
+that do not depend on the size: a histogram total against a closed form, and the
+window-summed autocorrelation against its re-ordering as one weighted sum over the
+series (every lag product counted once per window that covers it).
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rdf_100k_atom_water_box_single_frame_bit_exact(gpu):
+    """33 334 O + 66 666 H, L = 100, cutoff 49.9, 4 990 bins: 5e9 pairs in one frame."""
+    rng = np.random.default_rng(4)
+    n_per_species = [33_334, 66_666]
+    box = [100.0, 100.0, 100.0]
+    cutoff, nbins = np.float32(49.9), 4990
+    pos = [(rng.random((n, 1, 3), dtype=np.float32) * np.float32(100.0)) for n in n_per_species]
+    eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+    eng.accumulate(pos)
+    got = eng.read()
+    eng.close()
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
+    np.testing.assert_array_equal(got, ref)
+    # strict reference masks drop the first atom of each species
+    n_o, n_h = n_per_species[0] - 1, n_per_species[1] - 1
+    assert got[0].sum() <= n_o * (n_o - 1) // 2
+    assert got[1].sum() <= n_o * n_h
+    assert got[2].sum() <= n_h * (n_h - 1) // 2
+
+
+def test_rdf_10k_atoms_many_frames_total_is_additive(gpu):
+    """Accumulating 64 frames in one call equals the sum of per-frame histograms, and
+    sharding the tile pairs over four ranks changes nothing."""
+    n_per_species = [5000, 5000]
+    box = [65.0] * 3
+    cutoff, nbins = np.float32(32.4), 3240
+    n_frames = 64
+    dev = [gpu.DeviceArray((n, n_frames, 3), np.float32) for n in n_per_species]
+    for i, d in enumerate(dev):
+        d.fill_uniform(seed=77 + i, lo=0.0, hi=65.0)
+    whole = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+    whole.accumulate(dev)
+    total = whole.read()
+    whole.close()
+    parts = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+    for f in range(0, n_frames, 16):
+        for rank in range(4):
+            parts.accumulate(dev, frames=np.arange(f, f + 16, dtype=np.int64),
+                             shard_rank=rank, shard_count=4)
+    np.testing.assert_array_equal(parts.read(), total)
+    parts.close()
+    for d in dev:
+        d.free()
+
+
+@pytest.mark.parametrize("data_range", [500, 5000])
+def test_acf_million_frame_series_against_weighted_sum(gpu, data_range):
+    """[1, 1e6, 3] AR(1) series, correlation_time 1.  With windows w = 0..n_win-1 of
+    length D, sum_w sum_{n < D-m} P(w+n, m) = sum_t P(t, m) * c_m(t), where c_m(t)
+    counts the windows whose lag-m range covers frame t."""
+    rng = np.random.default_rng(5)
+    T, D = 1_000_000, data_range
+    phi = np.exp(-1.0 / 200.0)
+    noise = rng.normal(size=(T, 3))
+    from scipy.signal import lfilter
+    x = lfilter([1.0], [1.0, -phi], noise, axis=0).astype(np.float32)[None]
+    tau = np.arange(D)
+    n_win = T - D
+    acf, _ = gpu.acf_windows(x, 1, 0, n_win, tau)
+
+    x64 = x[0].astype(np.float64)
+    lags = np.unique(np.concatenate([np.arange(0, 8), np.linspace(8, D - 1, 25, dtype=int)]))
+    t = np.arange(T)
+    for m in lags:
+        prod = np.einsum("td,td->t", x64[: T - m], x64[m:])
+        tt = t[: T - m]
+        # windows w with w <= t <= w + D-1-m, 0 <= w <= n_win-1
+        lo = np.maximum(0, tt - (D - 1 - m))
+        hi = np.minimum(n_win - 1, tt)
+        count = np.clip(hi - lo + 1, 0, None)
+        expected = float(np.dot(prod, count)) / (D - m)
+        assert abs(acf[m] - expected) <= 1e-9 * abs(acf[0]), (m, acf[m], expected)
