@@ -138,6 +138,26 @@ __global__ __launch_bounds__(kThreads) void acf_partial_kernel(
   }
 }
 
+// Exclusive prefix sum of one double per thread over the block, in thread order.
+// `wave_tot` holds one slot per wave; the caller guarantees a barrier between two
+// scans (the window loops have one).  Contains one barrier.
+template <int kBlock>
+__device__ __forceinline__ double block_exclusive_scan(double v, double *wave_tot) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double up = __shfl_up(incl, off);
+    if (lane >= off) incl = incl + up;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  double base = 0.0;
+  for (int w = 0; w < wave; ++w) base = base + wave_tot[w];
+  return base + (incl - v);
+}
+
 // ---------------------------------------------------------------- ACF, stage B
 
 // One block walks over a contiguous range of windows.  Per-block results:
@@ -180,11 +200,7 @@ __global__ __launch_bounds__(kThreads) void acf_finish_kernel(
     double run = 0.0;
     for (int i = i0; i < i1; ++i)
       run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
-    tot[threadIdx.x] = run;
-    __syncthreads();
-    double offset = 0.0;
-    for (int t = 0; t < static_cast<int>(threadIdx.x); ++t) offset = offset + tot[t];
-    run = offset;
+    run = block_exclusive_scan<kThreads>(run, tot);
     const double count = static_cast<double>(w - w0 + 1);
     for (int i = i0; i < i1; ++i) {
       run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
@@ -229,19 +245,27 @@ __global__ __launch_bounds__(64) void acf_merge_kernel(
 // ------------------------------------------------------- ACF, sliding windows
 
 // Lag product P(t, m) = sum_s sum_d x_s[t][d] * x_s[t + m][d], from the series.
-template <typename T>
+// K > 0: the number of components at compile time; kSingle: exactly one series
+// (both let the compiler unroll the callers' loops over consecutive frames).
+template <typename T, int K, bool kSingle>
 struct SeriesProduct {
   const T *x;
   int64_t n_series, n_frames;
-  int k;
-  __device__ __forceinline__ double operator()(int64_t t, int m) const {
+  int k_runtime;
+  __device__ __forceinline__ double one(const T *a, int m) const {
+    const int k = (K > 0) ? K : k_runtime;
+    const T *b = a + static_cast<int64_t>(m) * k;
     double sum = 0.0;
-    for (int64_t s = 0; s < n_series; ++s) {
-      const T *a = x + (s * n_frames + t) * k;
-      const T *b = a + static_cast<int64_t>(m) * k;
-      for (int d = 0; d < k; ++d)
-        sum = fma(static_cast<double>(a[d]), static_cast<double>(b[d]), sum);
-    }
+#pragma unroll
+    for (int d = 0; d < k; ++d)
+      sum = fma(static_cast<double>(a[d]), static_cast<double>(b[d]), sum);
+    return sum;
+  }
+  __device__ __forceinline__ double operator()(int64_t t, int m) const {
+    const int k = (K > 0) ? K : k_runtime;
+    if (kSingle) return one(x + t * k, m);
+    double sum = 0.0;
+    for (int64_t s = 0; s < n_series; ++s) sum = sum + one(x + (s * n_frames + t) * k, m);
     return sum;
   }
 };
@@ -271,8 +295,8 @@ __global__ __launch_bounds__(kThreads) void band_combine_kernel(double *__restri
 // P(o + n, m) for the window origin o is computed directly for the first window
 // and updated by the 2*ct products that leave and enter for every later one.
 // Outputs as acf_finish_kernel, at block index block_offset + blockIdx.x.
-template <typename Product>
-__global__ __launch_bounds__(kThreads) void acf_slide_kernel(
+template <typename Product, int kBlock>
+__global__ __launch_bounds__(kBlock) void acf_slide_kernel(
     Product prod, int64_t ct, int64_t win_begin, int64_t n_win, int64_t windows_per_block,
     int R, double scale, double integral_scale, const double *__restrict__ time,
     int64_t block_offset, double *__restrict__ acf_blk, double *__restrict__ mean_blk,
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void acf_slide_kernel(
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *Wl = reinterpret_cast<double *>(lds_raw);  // [R] unnormalised window sums
   double *cs = Wl + R;                               // [R] window correlation
-  double *tot = cs + R;                              // [kThreads] segment totals
+  double *tot = cs + R;                              // [kBlock] segment totals
   const int64_t w0 = static_cast<int64_t>(blockIdx.x) * windows_per_block;
   const int64_t w1 = min(n_win, w0 + windows_per_block);
   const int64_t blk = block_offset + blockIdx.x;
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void acf_slide_kernel(
   double *mean = mean_blk + blk * (R - 1);
   double *m2 = m2_blk + blk * (R - 1);
   const int n_int = R - 1;
-  const int seg = (n_int + kThreads - 1) / kThreads;
+  const int seg = (n_int + kBlock - 1) / kBlock;
   const int i0 = min(n_int, static_cast<int>(threadIdx.x) * seg);
   const int i1 = min(n_int, i0 + seg);
   for (int i = i0; i < i1; ++i) {
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(kThreads) void acf_slide_kernel(
     m2[i] = 0.0;
   }
   const int64_t o0 = (win_begin + w0) * ct;
-  for (int m = threadIdx.x; m < R; m += kThreads) {
+  for (int m = threadIdx.x; m < R; m += kBlock) {
     acf[m] = 0.0;
     double sum = 0.0;
     for (int n = 0; n < R - m; ++n) sum = sum + prod(o0 + n, m);
@@ -305,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void acf_slide_kernel(
   for (int64_t w = w0; w < w1; ++w) {
     const int64_t o_prev = (win_begin + w - 1) * ct;
     __syncthreads();  // the previous window's reads of cs are complete
-    for (int m = threadIdx.x; m < R; m += kThreads) {
+    for (int m = threadIdx.x; m < R; m += kBlock) {
       double W = Wl[m];
       if (w > w0) {
         for (int64_t n = 0; n < ct; ++n)
@@ -321,11 +345,7 @@ __global__ __launch_bounds__(kThreads) void acf_slide_kernel(
     double run = 0.0;
     for (int i = i0; i < i1; ++i)
       run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
-    tot[threadIdx.x] = run;
-    __syncthreads();
-    double offset = 0.0;
-    for (int t = 0; t < static_cast<int>(threadIdx.x); ++t) offset = offset + tot[t];
-    run = offset;
+    run = block_exclusive_scan<kBlock>(run, tot);
     const double count = static_cast<double>(w - w0 + 1);
     for (int i = i0; i < i1; ++i) {
       run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
@@ -591,7 +611,9 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
   const int n_int = R > 1 ? R - 1 : 1;
   const bool slide = ti.identity && R >= 2 && 4 * correlation_time <= R;
   if (slide) {
-    const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + kThreads);
+    // four lags per thread at most before the block grows to 1024 threads
+    const int slide_block = (R > 1024) ? 1024 : 256;
+    const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + slide_block);
     const bool band = n_series > 8;
     // windows per block: enough to amortise the directly computed first window
     // (R/2 products per lag against 2*ct per slide), few enough to fill the chip
@@ -602,7 +624,10 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
       if (amortise > spread) amortise = spread;
       int64_t wpb = ceil_div(windows, 2048);
       if (wpb < amortise) wpb = amortise;
-      if (wpb > 512) wpb = 512;
+      // the cap bounds the drift of the running sums; long windows need more
+      // slides to pay for their first window
+      const int64_t cap = R > 512 ? R : 512;
+      if (wpb > cap) wpb = cap;
       if (wpb < 1) wpb = 1;
       return wpb;
     };
@@ -685,27 +710,51 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
         }
       }
       KernelTimer timer(MDX_SLOT_ACF_FINISH, stream);
-#define MDX_LAUNCH_SLIDE(PRODUCT_TYPE, PRODUCT)                                              \
+#define MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, BLOCK)                                      \
   do {                                                                                       \
     MDX_HIP(hipFuncSetAttribute(                                                             \
-        reinterpret_cast<const void *>(acf_slide_kernel<PRODUCT_TYPE>),                      \
+        reinterpret_cast<const void *>(acf_slide_kernel<PRODUCT_TYPE, BLOCK>),               \
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_s)));               \
-    hipLaunchKernelGGL(acf_slide_kernel<PRODUCT_TYPE>, dim3(static_cast<unsigned>(n_blocks)), \
-                       dim3(kThreads), lds_s, stream, PRODUCT, correlation_time,             \
-                       win_begin + ws, nw, wpb, R, scale, integral_scale, d_time_ptr,        \
-                       block_offset, d_acf.as<double>(), d_mean.as<double>(),                \
-                       d_m2.as<double>());                                                   \
+    hipLaunchKernelGGL((acf_slide_kernel<PRODUCT_TYPE, BLOCK>),                              \
+                       dim3(static_cast<unsigned>(n_blocks)), dim3(BLOCK), lds_s, stream,    \
+                       PRODUCT, correlation_time, win_begin + ws, nw, wpb, R, scale,         \
+                       integral_scale, d_time_ptr, block_offset, d_acf.as<double>(),         \
+                       d_mean.as<double>(), d_m2.as<double>());                              \
+  } while (0)
+#define MDX_LAUNCH_SLIDE(PRODUCT_TYPE, PRODUCT)                                              \
+  do {                                                                                       \
+    if (slide_block == 1024)                                                                 \
+      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 1024);                                       \
+    else                                                                                     \
+      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 256);                                        \
+  } while (0)
+#define MDX_LAUNCH_SLIDE_SERIES(TYPE)                                                        \
+  do {                                                                                       \
+    const TYPE *xs = static_cast<const TYPE *>(dx);                                          \
+    if (k == 3 && n_series == 1) {                                                           \
+      using P = SeriesProduct<TYPE, 3, true>;                                                \
+      P prod{xs, n_series, n_frames, k};                                                     \
+      MDX_LAUNCH_SLIDE(P, prod);                                                             \
+    } else if (k == 3) {                                                                     \
+      using P = SeriesProduct<TYPE, 3, false>;                                               \
+      P prod{xs, n_series, n_frames, k};                                                     \
+      MDX_LAUNCH_SLIDE(P, prod);                                                             \
+    } else {                                                                                 \
+      using P = SeriesProduct<TYPE, 0, false>;                                               \
+      P prod{xs, n_series, n_frames, k};                                                     \
+      MDX_LAUNCH_SLIDE(P, prod);                                                             \
+    }                                                                                        \
   } while (0)
       if (band) {
         BandProduct prod{d_C.as<double>(), t0, R};
         MDX_LAUNCH_SLIDE(BandProduct, prod);
       } else if (dtype == MDX_F32) {
-        SeriesProduct<float> prod{static_cast<const float *>(dx), n_series, n_frames, k};
-        MDX_LAUNCH_SLIDE(SeriesProduct<float>, prod);
+        MDX_LAUNCH_SLIDE_SERIES(float);
       } else {
-        SeriesProduct<double> prod{static_cast<const double *>(dx), n_series, n_frames, k};
-        MDX_LAUNCH_SLIDE(SeriesProduct<double>, prod);
+        MDX_LAUNCH_SLIDE_SERIES(double);
       }
+#undef MDX_LAUNCH_SLIDE_SERIES
+#undef MDX_LAUNCH_SLIDE_B
 #undef MDX_LAUNCH_SLIDE
       MDX_HIP(hipGetLastError());
       block_offset += n_blocks;
