@@ -36,6 +36,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxOwned = 16;  // (window, lag pair) items per thread in the ACF kernel
+constexpr int kSlidePer = 8;   // lags per thread in the sliding kernel
 
 // ------------------------------------------------------------------ staging
 
@@ -301,58 +302,92 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
     int R, double scale, double integral_scale, const double *__restrict__ time,
     int64_t block_offset, double *__restrict__ acf_blk, double *__restrict__ mean_blk,
     double *__restrict__ m2_blk) {
+  // A thread owns the lags m = tid + j * kBlock and the integral indices
+  // i0 + j, j < kSlidePer; their running values stay in registers.  LDS holds two
+  // images of the window correlation (so one barrier per window separates writers
+  // from readers) and the wave totals of the scan.
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  double *Wl = reinterpret_cast<double *>(lds_raw);  // [R] unnormalised window sums
-  double *cs = Wl + R;                               // [R] window correlation
-  double *tot = cs + R;                              // [kBlock] segment totals
+  double *cs_base = reinterpret_cast<double *>(lds_raw);  // [2][R]
+  double *tot = cs_base + 2 * static_cast<size_t>(R);     // [kBlock / 64]
   const int64_t w0 = static_cast<int64_t>(blockIdx.x) * windows_per_block;
   const int64_t w1 = min(n_win, w0 + windows_per_block);
   const int64_t blk = block_offset + blockIdx.x;
-  double *acf = acf_blk + blk * R;
-  double *mean = mean_blk + blk * (R - 1);
-  double *m2 = m2_blk + blk * (R - 1);
+  const int tid = threadIdx.x;
   const int n_int = R - 1;
-  const int seg = (n_int + kBlock - 1) / kBlock;
-  const int i0 = min(n_int, static_cast<int>(threadIdx.x) * seg);
+  const int seg = (n_int + kBlock - 1) / kBlock;  // <= kSlidePer, checked by the host
+  const int i0 = min(n_int, tid * seg);
   const int i1 = min(n_int, i0 + seg);
-  for (int i = i0; i < i1; ++i) {
-    mean[i] = 0.0;
-    m2[i] = 0.0;
-  }
+
+  double W[kSlidePer], acf[kSlidePer], norm[kSlidePer];
+  double mean[kSlidePer], m2[kSlidePer], dt[kSlidePer];
   const int64_t o0 = (win_begin + w0) * ct;
-  for (int m = threadIdx.x; m < R; m += kBlock) {
-    acf[m] = 0.0;
-    double sum = 0.0;
-    for (int n = 0; n < R - m; ++n) sum = sum + prod(o0 + n, m);
-    Wl[m] = sum;
+#pragma unroll
+  for (int j = 0; j < kSlidePer; ++j) {
+    const int m = tid + j * kBlock;
+    acf[j] = 0.0;
+    mean[j] = 0.0;
+    m2[j] = 0.0;
+    W[j] = 0.0;
+    norm[j] = 0.0;
+    dt[j] = 0.0;
+    if (m < R) {
+      norm[j] = scale / static_cast<double>(R - m);
+      double sum = 0.0;
+      for (int n = 0; n < R - m; ++n) sum = sum + prod(o0 + n, m);
+      W[j] = sum;
+    }
+    if (time != nullptr && i0 + j < i1) dt[j] = time[i0 + j + 1] - time[i0 + j];
   }
   for (int64_t w = w0; w < w1; ++w) {
     const int64_t o_prev = (win_begin + w - 1) * ct;
-    __syncthreads();  // the previous window's reads of cs are complete
-    for (int m = threadIdx.x; m < R; m += kBlock) {
-      double W = Wl[m];
-      if (w > w0) {
-        for (int64_t n = 0; n < ct; ++n)
-          W = W + (prod(o_prev + (R - m) + n, m) - prod(o_prev + n, m));
-        Wl[m] = W;
+    double *cs = cs_base + static_cast<size_t>((w - w0) & 1) * R;
+#pragma unroll
+    for (int j = 0; j < kSlidePer; ++j) {
+      const int m = tid + j * kBlock;
+      if (m < R) {
+        if (w > w0) {
+          double d = 0.0;
+          for (int64_t n = 0; n < ct; ++n)
+            d = d + (prod(o_prev + (R - m) + n, m) - prod(o_prev + n, m));
+          W[j] = W[j] + d;
+        }
+        const double c = W[j] * norm[j];
+        acf[j] = acf[j] + c;
+        cs[m] = c * integral_scale;
       }
-      const double c = W * (scale / static_cast<double>(R - m));
-      acf[m] = acf[m] + c;
-      cs[m] = c * integral_scale;
     }
     if (time == nullptr) continue;  // uniform: no integral requested
-    __syncthreads();
+    __syncthreads();  // cs complete; the other image was last read two barriers ago
+    double part[kSlidePer];
     double run = 0.0;
-    for (int i = i0; i < i1; ++i)
-      run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
+#pragma unroll
+    for (int j = 0; j < kSlidePer; ++j) {
+      part[j] = 0.0;
+      if (i0 + j < i1) {
+        part[j] = dt[j] * (cs[i0 + j + 1] + cs[i0 + j]) / 2.0;
+        run = run + part[j];
+      }
+    }
     run = block_exclusive_scan<kBlock>(run, tot);
     const double count = static_cast<double>(w - w0 + 1);
-    for (int i = i0; i < i1; ++i) {
-      run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
-      const double delta = run - mean[i];
-      const double mu = mean[i] + delta / count;
-      mean[i] = mu;
-      m2[i] = m2[i] + delta * (run - mu);
+#pragma unroll
+    for (int j = 0; j < kSlidePer; ++j) {
+      if (i0 + j < i1) {
+        run = run + part[j];
+        const double delta = run - mean[j];
+        const double mu = mean[j] + delta / count;
+        mean[j] = mu;
+        m2[j] = m2[j] + delta * (run - mu);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSlidePer; ++j) {
+    const int m = tid + j * kBlock;
+    if (m < R) acf_blk[blk * R + m] = acf[j];
+    if (i0 + j < i1) {
+      mean_blk[blk * (R - 1) + i0 + j] = mean[j];
+      m2_blk[blk * (R - 1) + i0 + j] = m2[j];
     }
   }
 }
@@ -613,7 +648,8 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
   if (slide) {
     // four lags per thread at most before the block grows to 1024 threads
     const int slide_block = (R > 1024) ? 1024 : 256;
-    const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + slide_block);
+    const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + slide_block / 64);
+    static_assert(8192 <= kSlidePer * 1024, "lags per thread");
     const bool band = n_series > 8;
     // windows per block: enough to amortise the directly computed first window
     // (R/2 products per lag against 2*ct per slide), few enough to fill the chip
