@@ -59,6 +59,18 @@ def parse_args():
     return ap.parse_args()
 
 
+def recorded_traffic(kernel_key: str):
+    """HBM-side bytes per launch of a kernel from the committed PMC summary (the
+    counters cannot be read from inside this process); None when not recorded."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+    try:
+        with open(path) as fh:
+            entry = json.load(fh)[kernel_key]
+        return entry["fetch_bytes_x2"] + entry["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main() -> None:
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +184,11 @@ def main() -> None:
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved_gbps / HBM_PEAK_GBPS,
-        "traffic": None,
+        "traffic": recorded_traffic("rdf_tile_kernel<false> grid=3358720")
+        if (fps == 1024 and not args.literal_kernel) else None,
+        "traffic_source": "profiles/r01_pmc.json: separate rocprofv3 --pmc FETCH_SIZE and "
+                          "WRITE_SIZE passes over this command; bytes per launch = "
+                          "2*FETCH_SIZE (gfx950 counts 128-B reads as 64 B) + WRITE_SIZE",
         "avg_launch_ms": tile_avg_ms,
         "launches": tile_launches,
         "algorithmic_bytes_per_launch": bytes_per_frame * frames_per_launch,
@@ -305,7 +321,9 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "roofline_atom_sum": {
             "kernel": "weighted_sum_kernel<float,4>", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None, "avg_launch_ms": avg_ms, "launches": sum_n,
+            "traffic": recorded_traffic("weighted_sum_kernel<float, 4> grid=1044480")
+            if n_frames == 16384 else None,
+            "avg_launch_ms": avg_ms, "launches": sum_n,
             "algorithmic_bytes_per_launch": bytes_per_launch},
         "acf_slide_kernel_ms": slide_ms / max(slide_n, 1),
     }

@@ -213,22 +213,24 @@ __global__ __launch_bounds__(kThreads) void acf_finish_kernel(
   }
 }
 
-// Merges the per-block results of acf_finish_kernel / acf_slide_kernel in block
-// order: out[0..R) = sum of the blocks' acf, out[R..2R-1) and out[2R-1..3R-2) = mean
-// and M2 of the running integral over all windows (pairwise update of Chan et al.).
-// Thread = lag / integral index.
-__global__ __launch_bounds__(64) void acf_merge_kernel(
+// Merges the per-block results of acf_finish_kernel / acf_slide_kernel: out[0..R) =
+// sum of the blocks' acf, out[R..2R-1) and out[2R-1..3R-2) = mean and M2 of the
+// running integral over all windows (pairwise update of Chan et al.).
+// One wave per lag / integral index: lane l folds blocks l, l + 64, ... in order,
+// then the 64 partial triples are combined by a fixed butterfly.
+__global__ __launch_bounds__(kThreads) void acf_merge_kernel(
     const double *__restrict__ acf_blk, const double *__restrict__ mean_blk,
     const double *__restrict__ m2_blk, const int64_t *__restrict__ counts, int64_t n_blocks,
     int R, double *__restrict__ out) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (i >= R) return;
+  const bool moments = (mean_blk != nullptr) && (i < R - 1);
   double total = 0.0;
-  for (int64_t b = 0; b < n_blocks; ++b) total = total + acf_blk[b * R + i];
-  out[i] = total;
-  if (mean_blk == nullptr || i >= R - 1) return;
   double n_a = 0.0, mean_a = 0.0, m2_a = 0.0;
-  for (int64_t b = 0; b < n_blocks; ++b) {
+  for (int64_t b = lane; b < n_blocks; b += 64) {
+    total = total + acf_blk[b * R + i];
+    if (!moments) continue;
     const double n_b = static_cast<double>(counts[b]);
     if (n_b <= 0.0) continue;
     const double mean_b = mean_blk[b * (R - 1) + i];
@@ -239,8 +241,28 @@ __global__ __launch_bounds__(64) void acf_merge_kernel(
     m2_a = m2_a + m2_b + delta * delta * (n_a * n_b / n_ab);
     n_a = n_ab;
   }
-  out[R + i] = mean_a;
-  out[R + (R - 1) + i] = m2_a;
+  for (int off = 32; off > 0; off >>= 1) {
+    total = total + __shfl_xor(total, off);
+    const double n_b = __shfl_xor(n_a, off);
+    const double mean_b = __shfl_xor(mean_a, off);
+    const double m2_b = __shfl_xor(m2_a, off);
+    const double n_ab = n_a + n_b;
+    if (n_ab > 0.0) {
+      // symmetric in (a, b): both partners arrive at the same triple
+      const double mean_ab = (n_a * mean_a + n_b * mean_b) / n_ab;
+      const double delta = mean_b - mean_a;
+      m2_a = m2_a + m2_b + delta * delta * (n_a * n_b / n_ab);
+      mean_a = mean_ab;
+      n_a = n_ab;
+    }
+  }
+  if (lane == 0) {
+    out[i] = total;
+    if (moments) {
+      out[R + i] = mean_a;
+      out[R + (R - 1) + i] = m2_a;
+    }
+  }
 }
 
 // ------------------------------------------------------- ACF, sliding windows
@@ -878,7 +900,8 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
                          hipMemcpyHostToDevice, stream));
   const bool merge_moments = want_integral && R > 1;
   MDX_TRY(d_out.alloc(sizeof(double) * (static_cast<size_t>(R) + 2 * n_int)));
-  hipLaunchKernelGGL(acf_merge_kernel, dim3(static_cast<unsigned>(ceil_div(R, 64))), dim3(64),
+  hipLaunchKernelGGL(acf_merge_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(R, kThreads / 64))), dim3(kThreads),
                      0, stream, d_acf.as<double>(),
                      merge_moments ? d_mean.as<double>() : nullptr,
                      merge_moments ? d_m2.as<double>() : nullptr, d_counts.as<int64_t>(),
