@@ -186,6 +186,45 @@ int mdx_thermal_flux(const void *stress, const void *vel, const void *ke,
                      int64_t n_frames, double *out, int out_location,
                      int accumulate);
 
+/* ------------------------------------------- coordinate transformations */
+/*
+ * Per-atom transformations of [n_atoms][n_frames][3] arrays into arrays of the same
+ * shape.  Arithmetic is float64 in the reference's operation order; out_dtype
+ * MDX_F32 rounds once at the store (the database stores float32).  Input and
+ * output may each live on the host or the device.
+ *
+ * CoordinateUnwrapper.transform_batch (mdsuite/transformations/
+ * unwrap_coordinates.py:51-81): image[t] = last_image - sum_{u<=t} round((pos[u] -
+ * pos[u-1]) / box) with round-half-even, out = pos + image * box.  last_pos and
+ * last_image ([n_atoms][3], host) carry the state across batches: read when
+ * have_carry != 0, always written with the batch's last frame.
+ */
+int mdx_unwrap_coordinates(const void *pos, int dtype, int location, int64_t n_atoms,
+                           int64_t n_frames, const double box[3], int have_carry,
+                           double *last_pos, double *last_image, void *out,
+                           int out_dtype, int out_location);
+/*
+ * Element-wise maps:
+ *   MDX_MAP_WRAP            x - floor(x / box) * box              CoordinateWrapper(center_box=False)
+ *   MDX_MAP_WRAP_CENTERED   the same on x + box/2, minus box/2    CoordinateWrapper(center_box=True)
+ *                           (mdsuite/transformations/wrap_coordinates.py:60-74)
+ *   MDX_MAP_SCALE           x * box      ScaleCoordinates (scale_coordinates.py:47-54)
+ *   MDX_MAP_UNWRAP_INDICES  x + aux * box, aux = image indices
+ *                           UnwrapViaIndices (unwrap_via_indices.py:48-57)
+ *   MDX_MAP_VELOCITY        (x[t+1] - x[t]) / params[0], last frame = the one before
+ *                           VelocityFromPositions (velocity_from_positions.py:42-58)
+ * params = box lengths, or {dt, unused, unused} for the velocity.  aux has the
+ * dtype and location of x and is read by MDX_MAP_UNWRAP_INDICES only.
+ */
+#define MDX_MAP_WRAP 0
+#define MDX_MAP_WRAP_CENTERED 1
+#define MDX_MAP_SCALE 2
+#define MDX_MAP_UNWRAP_INDICES 3
+#define MDX_MAP_VELOCITY 4
+int mdx_map_coordinates(int op, const void *x, const void *aux, int dtype, int location,
+                        int64_t n_atoms, int64_t n_frames, const double params[3],
+                        void *out, int out_dtype, int out_location);
+
 /* ------------------------------------------------- time-lag correlations */
 /*
  * Windowed autocorrelation, the ensemble loop of the Green-Kubo calculators:

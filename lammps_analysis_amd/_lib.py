@@ -88,6 +88,14 @@ SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_int]),
+    "mdx_unwrap_coordinates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int64, ctypes.c_int64, c_f64_p,
+                                              ctypes.c_int, c_f64_p, c_f64_p, ctypes.c_void_p,
+                                              ctypes.c_int, ctypes.c_int]),
+    "mdx_map_coordinates": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                           ctypes.c_int64, c_f64_p, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_int]),
     "mdx_acf_windows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,

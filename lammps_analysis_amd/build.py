@@ -20,7 +20,8 @@ LIB_DIR = PACKAGE_DIR / "lib"
 LIB_PATH = LIB_DIR / "libmdx.so"
 OBJ_DIR = PACKAGE_DIR / "build"
 
-SOURCES = ["mdx_runtime.hip", "mdx_rdf.hip", "mdx_reduce.hip", "mdx_corr.hip"]
+SOURCES = ["mdx_runtime.hip", "mdx_rdf.hip", "mdx_reduce.hip", "mdx_corr.hip",
+           "mdx_transform.hip"]
 
 HIPCC_FLAGS = [
     "-O3",

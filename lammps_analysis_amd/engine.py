@@ -301,6 +301,77 @@ def thermal_flux(stress: ArrayLike, vel: ArrayLike, ke: ArrayLike, pe: ArrayLike
     return out
 
 
+# ------------------------------------------------- coordinate transformations
+
+MAP_WRAP, MAP_WRAP_CENTERED, MAP_SCALE, MAP_UNWRAP_INDICES, MAP_VELOCITY = range(5)
+
+
+def _map_output(out, shape, out_dtype):
+    """(pointer, dtype code, location, array to return) of a transformation output."""
+    if isinstance(out, DeviceArray):
+        if tuple(out.shape) != tuple(shape):
+            raise ValueError(f"out must have shape {tuple(shape)}")
+        return out.ptr, _dtype_code(out.dtype), MDX_DEVICE, out
+    if out is None:
+        out = np.empty(shape, dtype=out_dtype)
+    if out.dtype not in (np.float32, np.float64) or not out.flags.c_contiguous \
+            or out.shape != tuple(shape):
+        raise ValueError(f"out must be a C-contiguous float array of shape {tuple(shape)}")
+    return out.ctypes.data, _dtype_code(out.dtype), MDX_HOST, out
+
+
+def _three(values, name: str) -> np.ndarray:
+    arr = np.ascontiguousarray(np.asarray(values, dtype=np.float64).reshape(-1))
+    if arr.size != 3:
+        raise ValueError(f"{name} must have three entries")
+    return arr
+
+
+def unwrap_coordinates(pos: ArrayLike, box, carry: Optional[dict] = None, out=None,
+                       out_dtype=np.float64):
+    """Unwrap ``pos`` ``[N, T, 3]`` by jump detection; returns ``(unwrapped, carry)``
+    with ``carry = {"last_pos": [N, 3], "last_image_box": [N, 3]}`` for the next batch."""
+    ptr, dt, loc, shape, keep = _as_input(pos)
+    if len(shape) != 3 or shape[2] != 3:
+        raise ValueError("pos must have shape (n_atoms, n_frames, 3)")
+    n_atoms, n_frames = shape[0], shape[1]
+    box_arr = _three(box, "box")
+    if carry is None:
+        last_pos = np.zeros((n_atoms, 3))
+        last_image = np.zeros((n_atoms, 3))
+    else:
+        last_pos = np.array(carry["last_pos"], dtype=np.float64).reshape(n_atoms, 3)
+        last_image = np.array(carry["last_image_box"], dtype=np.float64).reshape(n_atoms, 3)
+    optr, odt, oloc, result = _map_output(out, shape, out_dtype)
+    check(_lib.load().mdx_unwrap_coordinates(
+        ptr, dt, loc, n_atoms, n_frames, box_arr.ctypes.data_as(_lib.c_f64_p),
+        0 if carry is None else 1, last_pos.ctypes.data_as(_lib.c_f64_p),
+        last_image.ctypes.data_as(_lib.c_f64_p), optr, odt, oloc))
+    return result, {"last_pos": last_pos, "last_image_box": last_image}
+
+
+def map_coordinates(op: int, x: ArrayLike, params, aux: Optional[ArrayLike] = None, out=None,
+                    out_dtype=np.float64):
+    """Element-wise coordinate maps (``MAP_*``) of ``x`` ``[N, T, 3]``."""
+    ptr, dt, loc, shape, keep = _as_input(x)
+    if len(shape) != 3 or shape[2] != 3:
+        raise ValueError("x must have shape (n_atoms, n_frames, 3)")
+    aptr, keep_aux = None, None
+    if aux is not None:
+        if isinstance(x, DeviceArray) != isinstance(aux, DeviceArray):
+            raise ValueError("aux must live where x lives")
+        if not isinstance(aux, DeviceArray):
+            aux = np.asarray(aux, dtype=keep.dtype)
+        aptr, adt, aloc, ashape, keep_aux = _as_input(aux)
+        if tuple(ashape) != tuple(shape) or adt != dt:
+            raise ValueError("aux must have the shape and dtype of x")
+    par = _three(params, "params")
+    optr, odt, oloc, result = _map_output(out, shape, out_dtype)
+    check(_lib.load().mdx_map_coordinates(int(op), ptr, aptr, dt, loc, shape[0], shape[1],
+                                          par.ctypes.data_as(_lib.c_f64_p), optr, odt, oloc))
+    return result
+
+
 # -------------------------------------------------------------- correlations
 
 

@@ -58,6 +58,31 @@ class RunComputation:
         from ..transformations import ThermalFlux
         return self.transformation_wrapper(ThermalFlux)
 
+    @property
+    def CoordinateWrapper(self):
+        from ..transformations import CoordinateWrapper
+        return self.transformation_wrapper(CoordinateWrapper)
+
+    @property
+    def CoordinateUnwrapper(self):
+        from ..transformations import CoordinateUnwrapper
+        return self.transformation_wrapper(CoordinateUnwrapper)
+
+    @property
+    def ScaleCoordinates(self):
+        from ..transformations import ScaleCoordinates
+        return self.transformation_wrapper(ScaleCoordinates)
+
+    @property
+    def UnwrapViaIndices(self):
+        from ..transformations import UnwrapViaIndices
+        return self.transformation_wrapper(UnwrapViaIndices)
+
+    @property
+    def VelocityFromPositions(self):
+        from ..transformations import VelocityFromPositions
+        return self.transformation_wrapper(VelocityFromPositions)
+
     # ----------------------------------------------------------- calculators
 
     def _calculator(self, name: str):

@@ -1,15 +1,22 @@
-"""Transformations that produce the system series the Green-Kubo / Einstein-Helfand
-calculators correlate.  Each reduces per-atom arrays over the atom axis on the GPU."""
+"""Transformations: the atom reductions that produce the system series the Green-Kubo /
+Einstein-Helfand calculators correlate, and the per-atom coordinate transformations
+(unwrap, wrap, scale, finite-difference velocities).  All run on the GPU."""
 from .ionic_current import IonicCurrent
 from .momentum_flux import MomentumFlux
+from .scale_coordinates import ScaleCoordinates
 from .thermal_flux import ThermalFlux
 from .transformations import (CannotFindPropertyError, CannotFindTransformationError,
-                              MultiSpeciesTrafo, Transformations)
+                              MultiSpeciesTrafo, SingleSpeciesTrafo, Transformations)
 from .translational_dipole_moment import TranslationalDipoleMoment
+from .unwrap_coordinates import CoordinateUnwrapper
+from .unwrap_via_indices import UnwrapViaIndices
+from .velocity_from_positions import VelocityFromPositions
+from .wrap_coordinates import CoordinateWrapper
 
 __all__ = ["IonicCurrent", "MomentumFlux", "ThermalFlux", "TranslationalDipoleMoment",
-           "Transformations", "MultiSpeciesTrafo", "CannotFindPropertyError",
-           "CannotFindTransformationError"]
+           "CoordinateUnwrapper", "UnwrapViaIndices", "CoordinateWrapper", "ScaleCoordinates",
+           "VelocityFromPositions", "Transformations", "SingleSpeciesTrafo",
+           "MultiSpeciesTrafo", "CannotFindPropertyError", "CannotFindTransformationError"]
 
 # property name -> transformation that produces it (used by the calculators'
 # dependency resolution, mdsuite/calculators/transformations_reference.py of the

@@ -134,6 +134,32 @@ class Transformations:
             return per_sp_value
         return getattr(self.experiment, prop.name.lower(), None)
 
+    def get_prop_through_transformation(self, sp_name, prop):
+        """Produce a missing input property by running the transformation that yields
+        it (transformations.py:352-388 of the reference)."""
+        from .transformation_dict import property_to_transformation_dict
+
+        if prop not in property_to_transformation_dict:
+            raise CannotFindTransformationError(
+                f"was asked to get '{prop.name}' for '{sp_name}', but there is no "
+                "transformation to get that property")
+        trafo_cls = property_to_transformation_dict[prop]
+        if not isinstance(trafo_cls, collections.abc.Iterable):
+            self.experiment.cls_transformation_run(trafo_cls(), species=[sp_name])
+        else:
+            for trafo_class in trafo_cls:
+                try:
+                    self.experiment.cls_transformation_run(trafo_class(), species=[sp_name])
+                except CannotFindPropertyError:
+                    continue
+                break
+            else:
+                raise CannotFindTransformationError(
+                    f"was asked to get '{prop.name}' for '{sp_name}'. There are "
+                    f"transformations to get this property ({trafo_cls}), but none of them "
+                    "have the required data")
+        return self.find_property_per_config(sp_name, prop)
+
     def get_generator_type_spec_and_const_data(self, species_names):
         """(paths that are streamed, {species: {property: constant array}})."""
         paths = {}
@@ -147,10 +173,19 @@ class Transformations:
                     continue
                 val = self.find_property_single_val(species_name, prop)
                 if val is None:
-                    raise CannotFindPropertyError(
-                        f"While performing transformation '{self.output_property.name}': "
-                        f"Property '{prop.name}' for species '{species_name}' cannot be "
-                        "found in the simulation database nor in the simulation metadata")
+                    try:
+                        path = self.get_prop_through_transformation(species_name, prop)
+                    except CannotFindTransformationError:
+                        path = None
+                    if path is None:
+                        raise CannotFindPropertyError(
+                            f"While performing transformation "
+                            f"'{self.output_property.name}': Property '{prop.name}' for "
+                            f"species '{species_name}' cannot be found in the simulation "
+                            "database nor in the simulation metadata, nor can it be "
+                            "obtained by a transformation")
+                    paths[str.encode(path)] = prop
+                    continue
                 if not isinstance(val, collections.abc.Iterable):
                     val = [val]
                 val = np.asarray(val, dtype=self.dtype)[None, None, :]
@@ -160,6 +195,49 @@ class Transformations:
     @abc.abstractmethod
     def run_transformation(self, species: typing.Iterable[str] = None):
         raise NotImplementedError
+
+
+class SingleSpeciesTrafo(Transformations):
+    """Transformations applied to each species separately
+    (mdsuite/transformations/transformations.py:439-519 of the reference)."""
+
+    def run_transformation(self, species: typing.Iterable[str] = None) -> None:
+        if species is None:
+            species = list(self.experiment.species.keys())
+        for species_name in species:
+            if self.database.check_existence(join_path(species_name, self.output_property.name)):
+                self.logger.info(f"{self.output_property.name} already exists for "
+                                 f"{species_name}, skipping transformation")
+                continue
+            # Inputs are resolved before the output dataset is laid out: a
+            # transformation that cannot find its inputs then leaves no empty dataset
+            # behind that would make the next candidate skip the species.
+            paths, const_input_data = self.get_generator_type_spec_and_const_data(
+                [species_name])
+            const_input_data = const_input_data[species_name]
+            output_data_structure = self._prepare_database_entry(species_name)
+            self._prepare_monitors(list(paths.keys()))
+            batch_generator, batch_generator_args = self.data_manager.batch_generator()
+            carryover = None
+            for index, batch_dict in enumerate(batch_generator(*batch_generator_args)):
+                batch_dict.pop(str.encode("data_size"))
+                # the transformation only has to know about the property
+                batch_wo_species = {key.decode().split("/")[-1]: val
+                                    for key, val in batch_dict.items()}
+                batch_wo_species.update(const_input_data)
+                ret = self.transform_batch(batch_wo_species, carryover=carryover)
+                if isinstance(ret, tuple):
+                    transformed_batch, carryover = ret
+                else:
+                    transformed_batch = ret
+                self._save_output(data=transformed_batch,
+                                  data_structure=output_data_structure,
+                                  index=index * self.batch_size)
+
+    @abc.abstractmethod
+    def transform_batch(self, batch: typing.Dict[str, np.ndarray],
+                        carryover: typing.Any = None):
+        raise NotImplementedError("transformation of a batch must be implemented")
 
 
 class MultiSpeciesTrafo(Transformations):

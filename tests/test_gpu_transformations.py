@@ -1,0 +1,157 @@
+"""GPU parity of the per-atom coordinate transformations against the NumPy oracle.
+
+The kernels evaluate the reference's float64 expressions operation by operation, so
+the comparison is bit-exact (``assert_array_equal``), also after the float32 store.
+"""
+import numpy as np
+import pytest
+
+from oracle import transformations as ort
+
+pytestmark = pytest.mark.gpu
+
+BOX = np.array([1.1, 2.2, 3.3])
+
+
+def _walk(rng, n, t, box, step=0.08):
+    """Random walk wrapped into the box: frequent jumps across the faces."""
+    free = np.cumsum(rng.normal(scale=step, size=(n, t, 3)), axis=1) + rng.random((n, 1, 3)) * box
+    return free - np.floor(free / box) * box, free
+
+
+def test_unwrap_known_answer_of_the_reference(gpu):
+    """CI/unit_tests/transformations/test_transformations.py:144-188."""
+    pos = np.array([[[0.5, 0.1, 3.2]], [[0.6, 2.1, 0.9]], [[0.6, 2.1, 2.1]], [[0.6, 0.1, 0.1]]])
+    pos = np.swapaxes(pos, 0, 1)
+    carry = {"last_pos": np.array([[0.5, 0.1, 3.2]]), "last_image_box": np.array([[4.0, 0, 0]])}
+    out, new_carry = gpu.unwrap_coordinates(pos, BOX, carry=carry)
+    should_be = np.array([[[4 * 1.1 + 0.5, 0.1, 3.2]], [[4 * 1.1 + 0.6, -0.1, 4.2]],
+                          [[4 * 1.1 + 0.6, -0.1, 5.4]], [[4 * 1.1 + 0.6, 0.1, 6.7]]])
+    np.testing.assert_allclose(out, np.swapaxes(should_be, 0, 1), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(new_carry["last_pos"], [[0.6, 0.1, 0.1]])
+    np.testing.assert_array_equal(new_carry["last_image_box"], [[4, 0, 2]])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 2), (17, 255), (5, 256), (9, 1500)])
+def test_unwrap_matches_oracle_across_batches(gpu, dtype, shape):
+    rng = np.random.default_rng(21)
+    n, t = shape
+    wrapped, free = _walk(rng, n, t, BOX)
+    wrapped = wrapped.astype(dtype)
+    # whole trajectory at once
+    got, carry = gpu.unwrap_coordinates(wrapped, BOX)
+    ref, ref_carry = ort.unwrap_coordinates(wrapped, BOX)
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(carry["last_pos"], ref_carry["last_pos"])
+    np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+    if dtype == np.float64 and t > 2:
+        np.testing.assert_allclose(got - got[:, :1], free - free[:, :1], atol=1e-9)
+    # the same in three batches with the carry handed on, float32 store
+    carry = None
+    ref_carry = None
+    edges = [0, t // 3, 2 * t // 3, t]
+    for a, b in zip(edges[:-1], edges[1:]):
+        if a == b:
+            continue
+        piece = np.ascontiguousarray(wrapped[:, a:b])
+        got, carry = gpu.unwrap_coordinates(piece, BOX, carry=carry, out_dtype=np.float32)
+        ref, ref_carry = ort.unwrap_coordinates(piece, BOX, carryover=ref_carry)
+        assert got.dtype == np.float32
+        np.testing.assert_array_equal(got, ref.astype(np.float32))
+        np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+
+
+def test_unwrap_device_resident_input_and_output(gpu):
+    rng = np.random.default_rng(22)
+    wrapped, _ = _walk(rng, 40, 700, BOX)
+    wrapped = wrapped.astype(np.float32)
+    x = gpu.DeviceArray.from_numpy(wrapped)
+    y = gpu.DeviceArray(wrapped.shape, np.float32)
+    gpu.unwrap_coordinates(x, BOX, out=y)
+    ref, _ = ort.unwrap_coordinates(wrapped, BOX)
+    np.testing.assert_array_equal(y.to_numpy(), ref.astype(np.float32))
+    x.free()
+    y.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_element_wise_maps_match_oracle(gpu, dtype):
+    """The cases of CI/unit_tests/transformations/test_transformations.py:103-121,191-260
+    on larger arrays."""
+    rng = np.random.default_rng(23)
+    n, t = 37, 301
+    pos = ((rng.random((n, t, 3)) - 0.3) * 7.0).astype(dtype)
+    images = rng.integers(-10, 10, size=(n, t, 3)).astype(dtype)
+    np.testing.assert_array_equal(gpu.map_coordinates(gpu.MAP_WRAP, pos, BOX),
+                                  ort.wrap_coordinates(pos, BOX, center_box=False))
+    np.testing.assert_array_equal(gpu.map_coordinates(gpu.MAP_WRAP_CENTERED, pos, BOX),
+                                  ort.wrap_coordinates(pos, BOX, center_box=True))
+    np.testing.assert_array_equal(gpu.map_coordinates(gpu.MAP_SCALE, pos, BOX),
+                                  ort.scale_coordinates(pos, BOX))
+    np.testing.assert_array_equal(
+        gpu.map_coordinates(gpu.MAP_UNWRAP_INDICES, pos, BOX, aux=images),
+        ort.unwrap_via_indices(pos, images, BOX))
+    np.testing.assert_array_equal(
+        gpu.map_coordinates(gpu.MAP_VELOCITY, pos, [0.1 * 17, 0, 0]),
+        ort.velocity_from_positions(pos, 0.1, 17))
+    wrapped = gpu.map_coordinates(gpu.MAP_WRAP, pos, BOX)
+    assert np.all(wrapped >= 0) and np.all(wrapped <= BOX)
+    out32 = gpu.map_coordinates(gpu.MAP_SCALE, pos, BOX, out_dtype=np.float32)
+    np.testing.assert_array_equal(out32, ort.scale_coordinates(pos, BOX).astype(np.float32))
+
+
+def test_map_rejects_bad_arguments(gpu):
+    with pytest.raises(ValueError):
+        gpu.map_coordinates(gpu.MAP_VELOCITY, np.zeros((2, 1, 3)), [0.1, 0, 0])
+    with pytest.raises(ValueError):
+        gpu.map_coordinates(gpu.MAP_WRAP, np.zeros((2, 4, 3)), [1.0, 0.0, 1.0])
+    with pytest.raises(ValueError):
+        gpu.map_coordinates(gpu.MAP_UNWRAP_INDICES, np.zeros((2, 4, 3)), BOX)
+
+
+def test_transformation_chain_through_the_experiment(gpu, tmp_path):
+    """Scaled positions -> Positions -> Unwrapped_Positions -> Velocities_From_Positions:
+    VelocityFromPositions finds its missing input through the transformation that
+    yields it, which in turn asks for Positions (property_to_transformation_dict), in
+    several batches with the unwrapping carry handed across them."""
+    import os
+
+    import lammps_analysis_amd as mds
+    from lammps_analysis_amd.database.mdsuite_properties import mdsuite_properties
+    from lammps_analysis_amd.database.simulation_database import (SpeciesInfo,
+                                                                  TrajectoryChunkData,
+                                                                  TrajectoryMetadata)
+    from lammps_analysis_amd.file_io.script_input import ScriptInput
+
+    rng = np.random.default_rng(24)
+    n_part, n_step = 30, 1200
+    box = [4.0, 5.0, 6.0]
+    wrapped, _ = _walk(rng, n_part, n_step, np.array(box), step=0.3)
+    scaled = (wrapped / np.array(box)).astype(np.float32)          # [n, t, 3]
+    os.chdir(tmp_path)
+    with mds.utils.helpers.change_memory_fraction(desired_memory=0.0001):
+        project = mds.Project()
+        exp = project.add_experiment("chain", timestep=0.25, temperature=1.0, units="metal")
+        species = [SpeciesInfo(name="Ar", n_particles=n_part,
+                               properties=[mdsuite_properties.scaled_positions])]
+        metadata = TrajectoryMetadata(species_list=species, n_configurations=n_step,
+                                      sample_rate=2, box_l=box)
+        chunk = TrajectoryChunkData(species_list=species, chunk_size=n_step)
+        chunk.add_data(np.swapaxes(scaled, 0, 1), 0, "Ar", "Scaled_Positions")
+        exp.add_data(ScriptInput(data=chunk, metadata=metadata, name="chain"))
+        exp.run.VelocityFromPositions()
+        loaded = exp.load_matrix(species=["Ar"], property_name="Unwrapped_Positions")
+        unwrapped = np.asarray(loaded["Ar/Unwrapped_Positions"])
+        vel = np.asarray(exp.load_matrix(species=["Ar"],
+                                         property_name="Velocities_From_Positions")
+                         ["Ar/Velocities_From_Positions"])
+    pos_ref = ort.scale_coordinates(scaled, box).astype(np.float32)
+    unwrapped_ref, _ = ort.unwrap_coordinates(pos_ref, box)
+    np.testing.assert_array_equal(unwrapped, unwrapped_ref.astype(np.float32))
+    assert vel.shape == (n_part, n_step, 3)
+    # interior frames of a batch: forward differences of the stored unwrapped positions
+    ref_vel = ort.velocity_from_positions(unwrapped, 0.25, 2).astype(np.float32)
+    agree = np.all(vel == ref_vel, axis=(0, 2))
+    assert agree.mean() > 0.9          # all but the last frame of every batch
+    assert agree[0] and agree[1]

@@ -206,3 +206,40 @@ def test_rdf_ideal_gas_is_flat():
                                                   number_of_configurations=20, number_of_bins=50)
     y = np.asarray(out["Ar_Ar"]["y"])[10:]
     assert abs(np.mean(y) - 1.0) < 0.05
+
+
+# ------------------------------------------------ coordinate transformations
+
+def test_unwrap_coordinates_known_answer():
+    """CI/unit_tests/transformations/test_transformations.py:144-188 of the reference."""
+    from oracle import transformations as ort
+    box_l = [1.1, 2.2, 3.3]
+    pos = np.array([[[0.5, 0.1, 3.2]], [[0.6, 2.1, 0.9]], [[0.6, 2.1, 2.1]], [[0.6, 0.1, 0.1]]])
+    pos = np.swapaxes(pos, 0, 1)
+    carry = {"last_pos": np.array([[0.5, 0.1, 3.2]]), "last_image_box": np.array([[4.0, 0, 0]])}
+    out, new_carry = ort.unwrap_coordinates(pos, box_l, carryover=carry)
+    should_be = np.array([[[4 * 1.1 + 0.5, 0.1, 3.2]], [[4 * 1.1 + 0.6, -0.1, 4.2]],
+                          [[4 * 1.1 + 0.6, -0.1, 5.4]], [[4 * 1.1 + 0.6, 0.1, 6.7]]])
+    np.testing.assert_allclose(out, np.swapaxes(should_be, 0, 1), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(new_carry["last_pos"], [[0.6, 0.1, 0.1]])
+    np.testing.assert_array_equal(new_carry["last_image_box"], [[4, 0, 2]])
+
+
+def test_element_wise_coordinate_transformations():
+    """test_scale_coordinates :103-121, test_unwrap_via_indices :191-213,
+    test_velocity_from_positions :216-240, test_wrap_coordinates :243-262."""
+    from oracle import transformations as ort
+    rng = np.random.default_rng(5)
+    pos = rng.random((5, 7, 3))
+    box_l = np.array([1.1, 2.2, 3.3])
+    np.testing.assert_array_equal(ort.scale_coordinates(pos, box_l), pos * box_l[None, None])
+    box_im = rng.integers(-10, 10, size=(5, 7, 3)).astype(float)
+    np.testing.assert_array_equal(ort.unwrap_via_indices(pos, box_im, box_l),
+                                  pos + box_im * box_l[None, None])
+    vels = (pos[:, 1:, :] - pos[:, :-1, :]) / (0.1 * 17)
+    should_be = np.concatenate((vels, vels[:, -1:, :]), axis=1)
+    np.testing.assert_array_equal(ort.velocity_from_positions(pos, 0.1, 17), should_be)
+    wrapped = ort.wrap_coordinates(pos * 5 - 2, box_l, center_box=False)
+    assert np.all(wrapped >= 0) and np.all(wrapped < box_l)
+    centred = ort.wrap_coordinates(pos * 5 - 2, box_l, center_box=True)
+    assert np.all(np.abs(centred) <= box_l / 2)
