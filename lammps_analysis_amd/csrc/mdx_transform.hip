@@ -25,99 +25,199 @@ __device__ __forceinline__ void store_value(T *dst, double v) {
   *dst = static_cast<T>(v);
 }
 
+// floor(fl(v / box)) and rint(fl(v / box)) without the divide in the common case:
+// the product with the rounded reciprocal is within 2^-51 (relative) of the
+// correctly rounded quotient, so both round to the same integer unless the product
+// lies that close to an integer (floor) or to a half-integer (rint); only then the
+// IEEE divide decides.
+__device__ __forceinline__ double floor_quotient(double v, double box, double inv_box) {
+  const double q = v * inv_box;
+  const double near = fabs(q - rint(q));
+  if (__builtin_expect(near <= fabs(q) * 0x1p-50 + 0x1p-1000, 0)) return floor(v / box);
+  return floor(q);
+}
+__device__ __forceinline__ double rint_quotient(double v, double box, double inv_box) {
+  const double q = v * inv_box;
+  const double n = rint(q);
+  const double near = fabs(fabs(q - n) - 0.5);
+  if (__builtin_expect(near <= fabs(q) * 0x1p-50 + 0x1p-1000, 0)) return rint(v / box);
+  return n;
+}
+
 // ------------------------------------------------------------------ unwrap
 
 // One block per atom.  jump[t] = rint((pos[t] - pos[t-1]) / box) (half to even, as
 // tf.math.round); image[t] = last_image - sum_{u <= t} jump[u]; out = pos + image * box.
 // The jumps are integers, so their float64 prefix sums are exact in any order and
 // the block scan reproduces the sequential cumsum bit for bit.
+constexpr int kPerThread = 4;  // consecutive frames (unwrap) / elements (maps) per thread
+
 template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kThreads) void unwrap_kernel(
     const TIn *__restrict__ pos, int64_t n_frames, Box3 box, int have_carry,
     double *__restrict__ last_pos, double *__restrict__ last_image, TOut *__restrict__ out) {
+  // A chunk of kThreads * kPerThread frames goes through LDS both ways, so global
+  // accesses are contiguous while a thread walks over kPerThread consecutive frames.
+  constexpr int kChunk = kThreads * kPerThread;
   __shared__ double wave_tot[3][kThreads / 64];
+  __shared__ TIn in_s[3 + 3 * kChunk];  // [0..3): the frame before the chunk
+  __shared__ TOut out_s[3 * kChunk];
   const int64_t atom = blockIdx.x;
   const TIn *x = pos + atom * n_frames * 3;
   TOut *y = out + atom * n_frames * 3;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  double first_prev[3], base[3];
+  double base[3], inv_box[3];
   for (int d = 0; d < 3; ++d) {
-    first_prev[d] = have_carry ? last_pos[atom * 3 + d] : static_cast<double>(x[d]);
+    inv_box[d] = 1.0 / box.v[d];
     base[d] = have_carry ? last_image[atom * 3 + d] : 0.0;  // image before this chunk
   }
-  for (int64_t t0 = 0; t0 < n_frames; t0 += kThreads) {
-    const int64_t t = t0 + threadIdx.x;
-    const bool valid = t < n_frames;
-    double cur[3], incl[3];
-    for (int d = 0; d < 3; ++d) {
-      cur[d] = valid ? static_cast<double>(x[t * 3 + d]) : 0.0;
-      const double prev =
-          !valid ? 0.0 : (t == 0 ? first_prev[d] : static_cast<double>(x[(t - 1) * 3 + d]));
-      const double diff = cur[d] - prev;
-      incl[d] = valid ? rint(diff / box.v[d]) : 0.0;
+  for (int64_t t0 = 0; t0 < n_frames; t0 += kChunk) {
+    const int64_t n_here = min(static_cast<int64_t>(kChunk), n_frames - t0);
+    __syncthreads();  // the previous chunk's readers of in_s / out_s are done
+    for (int e = threadIdx.x; e < 3 * n_here; e += kThreads) in_s[3 + e] = x[t0 * 3 + e];
+    if (threadIdx.x < 3) {
+      if (t0 > 0)
+        in_s[threadIdx.x] = x[(t0 - 1) * 3 + threadIdx.x];
+      else if (!have_carry)
+        in_s[threadIdx.x] = x[threadIdx.x];
     }
+    __syncthreads();
+    const int fb = threadIdx.x * kPerThread;  // first frame of this thread in the chunk
+    double cur[kPerThread][3], cum[kPerThread][3], total[3];
+    for (int d = 0; d < 3; ++d) {
+      double prev = 0.0;
+      if (fb < n_here) {
+        // with a carry the frame before the very first one comes as float64
+        prev = (t0 == 0 && fb == 0 && have_carry) ? last_pos[atom * 3 + d]
+                                                  : static_cast<double>(in_s[3 * fb + d]);
+      }
+      double run = 0.0;
+#pragma unroll
+      for (int f = 0; f < kPerThread; ++f) {
+        const bool valid = fb + f < n_here;
+        cur[f][d] = valid ? static_cast<double>(in_s[3 + 3 * (fb + f) + d]) : 0.0;
+        if (valid) run = run + rint_quotient(cur[f][d] - prev, box.v[d], inv_box[d]);
+        cum[f][d] = run;
+        prev = cur[f][d];
+      }
+      total[d] = run;
+    }
+    double incl[3];
+    for (int d = 0; d < 3; ++d) incl[d] = total[d];
     for (int off = 1; off < 64; off <<= 1) {
       for (int d = 0; d < 3; ++d) {
         const double up = __shfl_up(incl[d], off);
         if (lane >= off) incl[d] = incl[d] + up;
       }
     }
-    __syncthreads();  // the previous chunk's readers of wave_tot are done
     if (lane == 63)
       for (int d = 0; d < 3; ++d) wave_tot[d][wave] = incl[d];
     __syncthreads();
-    double chunk_total[3];
     for (int d = 0; d < 3; ++d) {
       double before = 0.0, all = 0.0;
       for (int w = 0; w < kThreads / 64; ++w) {
         if (w < wave) before = before + wave_tot[d][w];
         all = all + wave_tot[d][w];
       }
-      chunk_total[d] = all;
-      const double image = -(incl[d] + before) + base[d];
-      if (valid) {
-        store_value(&y[t * 3 + d], cur[d] + image * box.v[d]);
-        if (t == n_frames - 1) {
-          last_pos[atom * 3 + d] = cur[d];
-          last_image[atom * 3 + d] = image;
+      const double preceding = (incl[d] - total[d]) + before;  // jumps before this thread
+#pragma unroll
+      for (int f = 0; f < kPerThread; ++f) {
+        if (fb + f < n_here) {
+          const double image = -(cum[f][d] + preceding) + base[d];
+          out_s[3 * (fb + f) + d] = static_cast<TOut>(cur[f][d] + image * box.v[d]);
+          if (t0 + fb + f == n_frames - 1) {
+            last_pos[atom * 3 + d] = cur[f][d];
+            last_image[atom * 3 + d] = image;
+          }
         }
       }
+      base[d] = base[d] - all;
     }
-    for (int d = 0; d < 3; ++d) base[d] = base[d] - chunk_total[d];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * n_here; e += kThreads) y[t0 * 3 + e] = out_s[e];
   }
 }
 
 // --------------------------------------------------------- element-wise maps
 
+// A thread owns kPerThread consecutive elements (16-byte accesses for float32).
 template <int OP, typename TIn, typename TOut>
 __global__ __launch_bounds__(kThreads) void map_kernel(const TIn *__restrict__ x,
                                                        const TIn *__restrict__ aux,
                                                        int64_t n_elements, int64_t n_frames,
-                                                       Box3 par, TOut *__restrict__ out) {
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (e >= n_elements) return;
-  const int d = static_cast<int>(e % 3);
-  const double v = static_cast<double>(x[e]);
-  double r;
-  if (OP == MDX_MAP_WRAP) {
-    r = v - floor(v / par.v[d]) * par.v[d];
-  } else if (OP == MDX_MAP_WRAP_CENTERED) {
-    const double half = par.v[d] / 2.0;
-    const double u = v + half;
-    r = (u - floor(u / par.v[d]) * par.v[d]) - half;
-  } else if (OP == MDX_MAP_SCALE) {
-    r = v * par.v[d];
-  } else if (OP == MDX_MAP_UNWRAP_INDICES) {
-    r = v + static_cast<double>(aux[e]) * par.v[d];
-  } else {  // MDX_MAP_VELOCITY: forward difference, the last frame repeats the one before
-    const int64_t t = (e / 3) % n_frames;
-    if (t + 1 < n_frames)
-      r = (static_cast<double>(x[e + 3]) - v) / par.v[0];
-    else
-      r = (v - static_cast<double>(x[e - 3])) / par.v[0];
+                                                       Box3 par, Box3 inv,
+                                                       TOut *__restrict__ out) {
+  const int64_t e0 =
+      (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * kPerThread;
+  if (e0 >= n_elements) return;
+  const bool full = e0 + kPerThread <= n_elements;
+  TIn in[kPerThread], ax[kPerThread];
+  if (full) {
+    struct alignas(sizeof(TIn) * kPerThread) Pack { TIn v[kPerThread]; };
+    const Pack p = *reinterpret_cast<const Pack *>(x + e0);
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) in[j] = p.v[j];
+    if (OP == MDX_MAP_UNWRAP_INDICES) {
+      const Pack q = *reinterpret_cast<const Pack *>(aux + e0);
+#pragma unroll
+      for (int j = 0; j < kPerThread; ++j) ax[j] = q.v[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) {
+      in[j] = (e0 + j < n_elements) ? x[e0 + j] : TIn(0);
+      if (OP == MDX_MAP_UNWRAP_INDICES) ax[j] = (e0 + j < n_elements) ? aux[e0 + j] : TIn(0);
+    }
   }
-  store_value(&out[e], r);
+  int d = static_cast<int>(e0 % 3);
+  int64_t t = (OP == MDX_MAP_VELOCITY) ? (e0 / 3) % n_frames : 0;
+  TOut res[kPerThread];
+#pragma unroll
+  for (int j = 0; j < kPerThread; ++j) {
+    const double v = static_cast<double>(in[j]);
+    double r;
+    if (OP == MDX_MAP_WRAP) {
+      r = v - floor_quotient(v, par.v[d], inv.v[d]) * par.v[d];
+    } else if (OP == MDX_MAP_WRAP_CENTERED) {
+      const double half = par.v[d] / 2.0;
+      const double u = v + half;
+      r = (u - floor_quotient(u, par.v[d], inv.v[d]) * par.v[d]) - half;
+    } else if (OP == MDX_MAP_SCALE) {
+      r = v * par.v[d];
+    } else if (OP == MDX_MAP_UNWRAP_INDICES) {
+      r = v + static_cast<double>(ax[j]) * par.v[d];
+    } else {  // MDX_MAP_VELOCITY: forward difference, the last frame repeats the one before
+      const int64_t e = e0 + j;
+      if (e < n_elements) {
+        if (t + 1 < n_frames) {
+          const double next = (j + 3 < kPerThread && full) ? static_cast<double>(in[j + 3])
+                                                           : static_cast<double>(x[e + 3]);
+          r = (next - v) / par.v[0];
+        } else {
+          r = (v - static_cast<double>(x[e - 3])) / par.v[0];
+        }
+      } else {
+        r = 0.0;
+      }
+    }
+    res[j] = static_cast<TOut>(r);
+    if (++d == 3) {
+      d = 0;
+      if (OP == MDX_MAP_VELOCITY && ++t == n_frames) t = 0;
+    }
+  }
+  if (full) {
+    struct alignas(sizeof(TOut) * kPerThread) PackOut { TOut v[kPerThread]; };
+    PackOut p;
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j) p.v[j] = res[j];
+    *reinterpret_cast<PackOut *>(out + e0) = p;
+  } else {
+#pragma unroll
+    for (int j = 0; j < kPerThread; ++j)
+      if (e0 + j < n_elements) out[e0 + j] = res[j];
+  }
 }
 
 int check_common(const void *x, int dtype, int location, int64_t n_atoms, int64_t n_frames,
@@ -217,13 +317,19 @@ int mdx_map_coordinates(int op, const void *x, const void *aux, int dtype, int l
   if (op == MDX_MAP_UNWRAP_INDICES)
     MDX_TRY(to_device(aux, location, n * dtype_size(dtype), aux_staged, stream, &daux));
   MDX_TRY(out_buffer(out, out_location, n * dtype_size(out_dtype), out_staged, &dout));
+  MDX_REQUIRE(reinterpret_cast<uintptr_t>(dx) % 32 == 0 &&
+                  reinterpret_cast<uintptr_t>(dout) % 32 == 0 &&
+                  reinterpret_cast<uintptr_t>(daux) % 32 == 0,
+              "device arrays must be 32-byte aligned");
   Box3 par{{params[0], params[1], params[2]}};
-  const dim3 grid(static_cast<unsigned>(ceil_div(static_cast<int64_t>(n), kThreads)));
-  MDX_REQUIRE(ceil_div(static_cast<int64_t>(n), kThreads) <= 2147483647LL, "array too large");
+  Box3 inv{{1.0 / params[0], 1.0 / params[1], 1.0 / params[2]}};
+  const int64_t n_blocks = ceil_div(static_cast<int64_t>(n), kThreads * kPerThread);
+  MDX_REQUIRE(n_blocks <= 2147483647LL, "array too large");
+  const dim3 grid(static_cast<unsigned>(n_blocks));
 #define MDX_LAUNCH_MAP_T(OP, TIN, TOUT)                                                    \
   hipLaunchKernelGGL((map_kernel<OP, TIN, TOUT>), grid, dim3(kThreads), 0, stream,         \
                      static_cast<const TIN *>(dx), static_cast<const TIN *>(daux),         \
-                     static_cast<int64_t>(n), n_frames, par, static_cast<TOUT *>(dout))
+                     static_cast<int64_t>(n), n_frames, par, inv, static_cast<TOUT *>(dout))
 #define MDX_LAUNCH_MAP(OP)                                                                 \
   do {                                                                                     \
     if (dtype == MDX_F32) {                                                                \
