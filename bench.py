@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=1024)
     ap.add_argument("--cpu-frames", type=int, default=24,
                     help="frames of the CPU-baseline sample (0 disables it)")
-    ap.add_argument("--gk-frames", type=int, default=16384,
+    ap.add_argument("--gk-frames", type=int, default=100000,
                     help="frames of the Green-Kubo side measurement (0 disables it)")
     ap.add_argument("--literal-kernel", action="store_true",
                     help="time the literal-arithmetic kernel instead of the table kernel")
@@ -60,13 +60,17 @@ def parse_args():
 
 
 def recorded_traffic(kernel_key: str):
-    """HBM-side bytes per launch of a kernel from the committed PMC summary (the
-    counters cannot be read from inside this process); None when not recorded."""
+    """HBM-side bytes per launch of the kernel whose summary key starts with
+    ``kernel_key``, from the committed PMC summary of this command with default sizes
+    (the counters cannot be read from inside this process); None when not recorded."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
     try:
         with open(path) as fh:
-            entry = json.load(fh)[kernel_key]
-        return entry["fetch_bytes_x2"] + entry["write_bytes"]
+            table = json.load(fh)
+        entries = [v for k, v in table.items() if k.startswith(kernel_key)]
+        if len(entries) != 1:
+            return None
+        return entries[0]["fetch_bytes_x2"] + entries[0]["write_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -321,8 +325,8 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "roofline_atom_sum": {
             "kernel": "weighted_sum_kernel<float,4>", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": recorded_traffic("weighted_sum_kernel<float, 4> grid=1044480")
-            if n_frames == 16384 else None,
+            "traffic": recorded_traffic("weighted_sum_kernel<float, 4>")
+            if n_frames == 100000 else None,
             "avg_launch_ms": avg_ms, "launches": sum_n,
             "algorithmic_bytes_per_launch": bytes_per_launch},
         "acf_slide_kernel_ms": slide_ms / max(slide_n, 1),
