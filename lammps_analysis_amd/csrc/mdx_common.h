@@ -24,6 +24,8 @@ int fail(int code, const char *fmt, ...);
 
 // The library stream of the current device (created on first use).
 int get_stream(hipStream_t *stream);
+// Second per-device stream, for host-to-device copies that overlap with kernels.
+int get_copy_stream(hipStream_t *stream);
 
 #define MDX_HIP(call)                                                          \
   do {                                                                         \

@@ -471,6 +471,12 @@ struct mdx_rdf_s {
   int shard_rank = 0, shard_count = 1;
   int64_t n_pairs_shard = 0;
   std::vector<const void *> uploaded_ptrs;  // content of d_species_ptr
+  void *pinned[2] = {nullptr, nullptr};     // page-locked staging of host input
+  size_t pinned_bytes = 0;
+  ~mdx_rdf_s() {
+    for (void *p : pinned)
+      if (p != nullptr) (void)hipHostFree(p);
+  }
 };
 
 namespace {
@@ -491,6 +497,169 @@ int upload_shard(mdx_rdf_s *h, int rank, int count, hipStream_t stream) {
   h->shard_rank = rank;
   h->shard_count = count;
   h->n_pairs_shard = static_cast<int64_t>(mine.size());
+  return MDX_OK;
+}
+
+}  // namespace
+
+namespace {
+
+// Packs frames [f0, f0 + nf) of the species arrays behind `species_ptr` (or the listed
+// frames) and histograms them with this handle's shard of tile pairs.  d_packed /
+// d_wrapped must hold nf frames.  `packed_done`, if given, is recorded once the
+// source arrays have been read.
+int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_ptr,
+                          const int64_t *d_frames, int64_t f0, int64_t frame_stride, int nf,
+                          hipStream_t stream, hipEvent_t packed_done) {
+  const bool literal = (h->flags & MDX_RDF_LITERAL_KERNEL) != 0u;
+  dim3 pgrid(static_cast<unsigned>(ceil_div(h->n_pad, 64)),
+             static_cast<unsigned>(ceil_div(nf, 16)));
+  {
+    KernelTimer timer(MDX_SLOT_RDF_PACK, stream);
+    if (dtype == MDX_F32) {
+      hipLaunchKernelGGL(rdf_pack_kernel<float>, pgrid, dim3(256), 0, stream, species_ptr,
+                         h->d_slot_species.as<int32_t>(), h->d_slot_atom.as<int32_t>(),
+                         d_frames, f0, frame_stride, nf, h->n_pad, h->d_packed.as<float>());
+    } else {
+      hipLaunchKernelGGL(rdf_pack_kernel<double>, pgrid, dim3(256), 0, stream, species_ptr,
+                         h->d_slot_species.as<int32_t>(), h->d_slot_atom.as<int32_t>(),
+                         d_frames, f0, frame_stride, nf, h->n_pad, h->d_packed.as<float>());
+    }
+  }
+  MDX_HIP(hipGetLastError());
+  if (packed_done != nullptr) MDX_HIP(hipEventRecord(packed_done, stream));
+  if (h->n_pairs_shard == 0) return MDX_OK;
+  if (!literal) {
+    hipLaunchKernelGGL(rdf_extent_kernel, dim3(static_cast<unsigned>(nf)), dim3(256), 0,
+                       stream, h->d_packed.as<float>(), h->n_pad, h->params,
+                       h->d_wrapped.as<int32_t>());
+    MDX_HIP(hipGetLastError());
+  }
+  // frames per block: large enough to amortise the histogram flush, small
+  // enough to keep several thousand blocks in flight
+  int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 8192;
+  if (fpg < 1) fpg = 1;
+  if (fpg > kMaxFramesPerGroup) fpg = kMaxFramesPerGroup;
+  dim3 grid(static_cast<unsigned>(h->n_pairs_shard),
+            static_cast<unsigned>(ceil_div(nf, fpg)));
+  KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
+  if (literal) {
+    hipLaunchKernelGGL(rdf_tile_kernel<true>, grid, dim3(kTile), h->lds_bytes, stream,
+                       h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
+                       h->d_pairs_shard.as<TilePair>(), h->params,
+                       static_cast<const float *>(nullptr),
+                       static_cast<const int32_t *>(nullptr), h->lds_hist_words,
+                       h->lds_thr_words, h->d_hist.as<unsigned long long>());
+  } else {
+    hipLaunchKernelGGL(rdf_tile_kernel<false>, grid, dim3(kTile), h->lds_bytes, stream,
+                       h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
+                       h->d_pairs_shard.as<TilePair>(), h->params,
+                       h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
+                       h->lds_hist_words, h->lds_thr_words,
+                       h->d_hist.as<unsigned long long>());
+  }
+  MDX_HIP(hipGetLastError());
+  return MDX_OK;
+}
+
+// Events of the copy/compute hand-over; on every exit path both streams are drained
+// before the staging blocks go back to the cache.
+struct EventPairGuard {
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t streams[2] = {nullptr, nullptr};
+  ~EventPairGuard() {
+    for (hipStream_t s : streams)
+      if (s != nullptr) (void)hipStreamSynchronize(s);
+    for (hipEvent_t e : ev)
+      if (e != nullptr) (void)hipEventDestroy(e);
+  }
+};
+
+int accumulate_host_pipelined(mdx_rdf_s *h, const void *const *species_pos, int dtype,
+                              int64_t frame_stride, int64_t n_frames, hipStream_t stream) {
+  hipStream_t copy_stream;
+  MDX_TRY(get_copy_stream(&copy_stream));
+  const size_t elem = dtype_size(dtype);
+  // block size: a quarter of the call, between 64 and 512 frames
+  int64_t block = n_frames / 4;
+  if (block < 64) block = 64;
+  if (block > 512) block = 512;
+  const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
+  MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(block)));
+  MDX_TRY(h->d_wrapped.reserve(sizeof(int32_t) * static_cast<size_t>(block)));
+
+  // One staging image per block parity: all species back to back, each as
+  // [atoms][block][3]; a page-locked twin on the host is filled row by row (a row =
+  // the block's frames of one atom, contiguous in the caller's array) and sent with
+  // one asynchronous copy.
+  const int ns = h->n_species;
+  std::vector<size_t> offset(ns + 1, 0);
+  for (int s = 0; s < ns; ++s) {
+    if (h->n_per_species[s] > 0)
+      MDX_REQUIRE(species_pos[s] != nullptr, "positions of species %d are null", s);
+    offset[s + 1] = offset[s] + static_cast<size_t>(h->n_per_species[s]) * block * 3 * elem;
+  }
+  const size_t image_bytes = offset[ns];
+  if (h->pinned_bytes < image_bytes) {
+    MDX_HIP(hipStreamSynchronize(copy_stream));
+    for (void *&p : h->pinned) {
+      if (p != nullptr) (void)hipHostFree(p);
+      p = nullptr;
+    }
+    h->pinned_bytes = 0;
+    for (void *&p : h->pinned) MDX_HIP(hipHostMalloc(&p, image_bytes, hipHostMallocDefault));
+    h->pinned_bytes = image_bytes;
+  }
+  DeviceBuffer staged[2];
+  DeviceBuffer d_table;
+  EventPairGuard events;  // [0,1] copied, [2,3] consumed; declared after the buffers
+  events.streams[0] = stream;
+  events.streams[1] = copy_stream;
+  std::vector<const void *> table(2 * static_cast<size_t>(ns), nullptr);
+  for (int b = 0; b < 2; ++b) {
+    MDX_TRY(staged[b].alloc(image_bytes));
+    for (int s = 0; s < ns; ++s)
+      table[b * ns + s] = static_cast<const char *>(staged[b].ptr) + offset[s];
+  }
+  MDX_TRY(d_table.alloc(sizeof(void *) * table.size()));
+  MDX_HIP(hipMemcpyAsync(d_table.ptr, table.data(), sizeof(void *) * table.size(),
+                         hipMemcpyHostToDevice, stream));
+  for (hipEvent_t &e : events.ev) MDX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  // the staging blocks may have been used by earlier work on the compute stream
+  MDX_HIP(hipEventRecord(events.ev[2], stream));
+  MDX_HIP(hipStreamWaitEvent(copy_stream, events.ev[2], 0));
+
+  int64_t index = 0;
+  int64_t step = 0;
+  for (int64_t f0 = 0; f0 < n_frames; f0 += step, ++index) {
+    const int b = static_cast<int>(index & 1);
+    // a short first block: its copy is the only one no kernel hides
+    step = (index == 0) ? std::min<int64_t>(block, 48) : block;
+    const int nf = static_cast<int>(std::min<int64_t>(step, n_frames - f0));
+    if (index >= 2) {
+      // the page-locked twin is free once its copy has left, the device image once
+      // the pack kernel has read it
+      MDX_HIP(hipEventSynchronize(events.ev[b]));
+      MDX_HIP(hipStreamWaitEvent(copy_stream, events.ev[2 + b], 0));
+    }
+    const size_t row = static_cast<size_t>(nf) * 3 * elem;
+    char *twin = static_cast<char *>(h->pinned[b]);
+    for (int s = 0; s < ns; ++s) {
+      const char *src = static_cast<const char *>(species_pos[s]) + f0 * 3 * elem;
+      char *dst = twin + offset[s];
+      const size_t pitch = static_cast<size_t>(frame_stride) * 3 * elem;
+      for (int64_t a = 0; a < h->n_per_species[s]; ++a)
+        memcpy(dst + static_cast<size_t>(a) * row, src + static_cast<size_t>(a) * pitch, row);
+    }
+    MDX_HIP(hipMemcpyAsync(staged[b].ptr, twin, image_bytes, hipMemcpyHostToDevice,
+                           copy_stream));
+    MDX_HIP(hipEventRecord(events.ev[b], copy_stream));
+    MDX_HIP(hipStreamWaitEvent(stream, events.ev[b], 0));
+    MDX_TRY(histogram_frame_block(h, dtype, d_table.as<const void *>() + b * ns, nullptr, 0, nf,
+                                  nf, stream, events.ev[2 + b]));
+  }
+  MDX_HIP(hipStreamSynchronize(stream));
+  MDX_HIP(hipStreamSynchronize(copy_stream));
   return MDX_OK;
 }
 
@@ -701,6 +870,12 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
   MDX_TRY(get_stream(&stream));
   MDX_TRY(upload_shard(h, shard_rank, shard_count, stream));
 
+  // Host input with a contiguous frame range: blocks of frames are copied on a
+  // second stream into two alternating staging sets while the previous block is
+  // being histogrammed.
+  if (location == MDX_HOST && frames == nullptr && n_frames >= 128)
+    return accumulate_host_pipelined(h, species_pos, dtype, frame_stride, n_frames, stream);
+
   // species arrays on the device
   std::vector<DeviceBuffer> staged(location == MDX_HOST ? h->n_species : 0);
   std::vector<const void *> ptrs(h->n_species, nullptr);
@@ -740,60 +915,11 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
   if (chunk > 32768) chunk = 32768;
   MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(chunk)));
   MDX_TRY(h->d_wrapped.reserve(sizeof(int32_t) * static_cast<size_t>(chunk)));
-
-  const bool literal = (h->flags & MDX_RDF_LITERAL_KERNEL) != 0u;
   for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = static_cast<int>(std::min<int64_t>(chunk, n_frames - f0));
-    dim3 pgrid(static_cast<unsigned>(ceil_div(h->n_pad, 64)),
-               static_cast<unsigned>(ceil_div(nf, 16)));
-    {
-    KernelTimer timer(MDX_SLOT_RDF_PACK, stream);
-    if (dtype == MDX_F32) {
-      hipLaunchKernelGGL(rdf_pack_kernel<float>, pgrid, dim3(256), 0, stream,
-                         h->d_species_ptr.as<const void *>(),
-                         h->d_slot_species.as<int32_t>(), h->d_slot_atom.as<int32_t>(),
-                         d_frames ? d_frames + f0 : nullptr, f0, frame_stride, nf, h->n_pad,
-                         h->d_packed.as<float>());
-    } else {
-      hipLaunchKernelGGL(rdf_pack_kernel<double>, pgrid, dim3(256), 0, stream,
-                         h->d_species_ptr.as<const void *>(),
-                         h->d_slot_species.as<int32_t>(), h->d_slot_atom.as<int32_t>(),
-                         d_frames ? d_frames + f0 : nullptr, f0, frame_stride, nf, h->n_pad,
-                         h->d_packed.as<float>());
-    }
-    }
-    MDX_HIP(hipGetLastError());
-    if (h->n_pairs_shard == 0) continue;
-    if (!literal) {
-      hipLaunchKernelGGL(rdf_extent_kernel, dim3(static_cast<unsigned>(nf)), dim3(256), 0,
-                         stream, h->d_packed.as<float>(), h->n_pad, h->params,
-                         h->d_wrapped.as<int32_t>());
-      MDX_HIP(hipGetLastError());
-    }
-    // frames per block: large enough to amortise the histogram flush, small
-    // enough to keep several thousand blocks in flight
-    int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 8192;
-    if (fpg < 1) fpg = 1;
-    if (fpg > kMaxFramesPerGroup) fpg = kMaxFramesPerGroup;
-    dim3 grid(static_cast<unsigned>(h->n_pairs_shard),
-              static_cast<unsigned>(ceil_div(nf, fpg)));
-    KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
-    if (literal) {
-      hipLaunchKernelGGL(rdf_tile_kernel<true>, grid, dim3(kTile), h->lds_bytes, stream,
-                         h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
-                         h->d_pairs_shard.as<TilePair>(), h->params,
-                         static_cast<const float *>(nullptr),
-                         static_cast<const int32_t *>(nullptr), h->lds_hist_words,
-                         h->lds_thr_words, h->d_hist.as<unsigned long long>());
-    } else {
-      hipLaunchKernelGGL(rdf_tile_kernel<false>, grid, dim3(kTile), h->lds_bytes, stream,
-                         h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
-                         h->d_pairs_shard.as<TilePair>(), h->params,
-                         h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
-                         h->lds_hist_words, h->lds_thr_words,
-                         h->d_hist.as<unsigned long long>());
-    }
-    MDX_HIP(hipGetLastError());
+    MDX_TRY(histogram_frame_block(h, dtype, h->d_species_ptr.as<const void *>(),
+                                  d_frames ? d_frames + f0 : nullptr, f0, frame_stride, nf,
+                                  stream, nullptr));
   }
   if (location == MDX_HOST) {
     // staged copies are released when this function returns

@@ -120,6 +120,20 @@ void pool_trim() {
   for (int dev = 0; dev < kMaxDevices; ++dev) trim_device_locked(dev);
 }
 
+static hipStream_t g_copy_streams[kMaxDevices] = {nullptr};
+
+int get_copy_stream(hipStream_t *stream) {
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices)
+    return fail(MDX_ERR_DEVICE, "device index %d out of range", dev);
+  if (g_copy_streams[dev] == nullptr) {
+    MDX_HIP(hipStreamCreateWithFlags(&g_copy_streams[dev], hipStreamNonBlocking));
+  }
+  *stream = g_copy_streams[dev];
+  return MDX_OK;
+}
+
 int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
               hipStream_t stream, const void **dptr) {
   if (src == nullptr) return fail(MDX_ERR_INVALID_ARGUMENT, "null data pointer");

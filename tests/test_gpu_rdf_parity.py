@@ -189,3 +189,25 @@ def test_box_edge_coordinates_half_box_ties(gpu):
     for literal in (True, False):
         got = _gpu_hist(gpu, pos, n_per_species, box, cutoff, nbins, literal=literal)
         np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_host_input_is_streamed_in_blocks(gpu, dtype):
+    """Host arrays with 128 or more contiguous frames are copied block by block on a
+    second stream while the previous block is histogrammed (two alternating staging
+    sets, a ragged last block); the counts equal those of the one-shot paths."""
+    rng = np.random.default_rng(31)
+    n_per_species = [150, 0, 100]
+    box = [10.0, 11.0, 12.0]
+    cutoff, nbins = np.float32(4.9), 490
+    n_frames = 333
+    pos = [p.astype(dtype) for p in _positions(rng, n_per_species, n_frames, box)]
+    streamed = _gpu_hist(gpu, pos, n_per_species, box, cutoff, nbins)
+    resident = _gpu_hist(gpu, pos, n_per_species, box, cutoff, nbins, device=True)
+    listed = _gpu_hist(gpu, pos, n_per_species, box, cutoff, nbins,
+                       frames=np.arange(n_frames, dtype=np.int64))
+    np.testing.assert_array_equal(streamed, resident)
+    np.testing.assert_array_equal(streamed, listed)
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0).astype(np.float32), n_per_species, box,
+                            cutoff, nbins)
+    np.testing.assert_array_equal(streamed, ref)
