@@ -256,6 +256,30 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
                     const double *time, double *acf_sum, double *integral_mean,
                     double *integral_m2, int64_t *n_windows);
 /*
+ * Windowed cross-correlation minus a self term, the ensemble loop of
+ * GreenKuboDistinctDiffusionCoefficients (mdsuite/calculators/
+ * green_kubo_distinct_diffusion_coefficients.py:176-267 with correlate,
+ * mdsuite/utils/calculator_helper_methods.py:110-148).  The reference averages
+ * jnp.correlate(a_i, b_j, "full")[D-1:] over all atom pairs (i, j); the correlation
+ * is bilinear, so that average equals the correlation of the two species-mean
+ * series a, b ([n_frames][k]).  For every window w (origin o = w * correlation_time)
+ * and lag m < data_range, without the 1/(D-m) factor of the autocorrelation:
+ *   c_w[m] = cross_weight * sum_{n < D-m} sum_d a[o+n+m][d] * b[o+n][d]
+ *          - self_weight  * sum_s sum_{n < D-m} sum_d x_s[o+n+m][d] * x_s[o+n][d]
+ * with x = self_atoms [n_self_atoms][n_frames][k] (NULL: no self term).
+ *   cf_sum[m]       += sum_w c_w[m]
+ *   integral_mean/m2 = mean and M2 over windows of the running trapezoid integral
+ *                      of c_w over `time`, as in mdx_acf_windows (time NULL: skipped)
+ * Accumulation is float64 (the reference's JAX default is float32).
+ */
+int mdx_ccf_windows(const void *a, const void *b, const void *self_atoms, int dtype,
+                    int location, int64_t n_self_atoms, int64_t n_frames, int k,
+                    int64_t correlation_time, int64_t win_begin, int64_t win_end,
+                    int data_range, double cross_weight, double self_weight,
+                    const double *time, double *cf_sum, double *integral_mean,
+                    double *integral_m2, int64_t *n_windows);
+
+/*
  * Windowed mean-square displacement, the ensemble loop of the Einstein
  * calculators: msd_sum[i] += scale * sum_w sum_s sum_d
  *      (x[s][w*ct + tau[i]][d] - x[s][w*ct][d])^2

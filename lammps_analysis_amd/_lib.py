@@ -102,6 +102,12 @@ SIGNATURES = {
                                        c_i32_p, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_double, c_f64_p, c_f64_p, c_f64_p, c_f64_p,
                                        c_i64_p]),
+    "mdx_ccf_windows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                       ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_double, c_f64_p, c_f64_p,
+                                       c_f64_p, c_f64_p, c_i64_p]),
     "mdx_msd_windows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,

@@ -1,6 +1,9 @@
 """Calculators of the accelerated path (same names as mdsuite.calculators)."""
 from .einstein_diffusion_coefficients import EinsteinDiffusionCoefficients
+from .einstein_distinct_diffusion_coefficients import EinsteinDistinctDiffusionCoefficients
 from .einstein_helfand_ionic_conductivity import EinsteinHelfandIonicConductivity
+from .green_kubo_distinct_diffusion_coefficients import \
+    GreenKuboDistinctDiffusionCoefficients
 from .green_kubo_ionic_conductivity import GreenKuboIonicConductivity
 from .green_kubo_self_diffusion_coefficients import GreenKuboDiffusionCoefficients
 from .green_kubo_thermal_conductivity import GreenKuboThermalConductivity
@@ -8,7 +11,8 @@ from .green_kubo_viscosity import GreenKuboViscosity
 from .green_kubo_viscosity_flux import GreenKuboViscosityFlux
 from .radial_distribution_function import RadialDistributionFunction
 
-__all__ = ["EinsteinDiffusionCoefficients", "EinsteinHelfandIonicConductivity",
+__all__ = ["EinsteinDiffusionCoefficients", "EinsteinDistinctDiffusionCoefficients",
+           "GreenKuboDistinctDiffusionCoefficients", "EinsteinHelfandIonicConductivity",
            "GreenKuboIonicConductivity", "GreenKuboDiffusionCoefficients",
            "GreenKuboThermalConductivity", "GreenKuboViscosity", "GreenKuboViscosityFlux",
            "RadialDistributionFunction"]

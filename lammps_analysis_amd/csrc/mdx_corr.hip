@@ -304,6 +304,30 @@ struct BandProduct {
   }
 };
 
+// Cross product of two series minus a weighted band table:
+//   P(t, m) = cross_weight * sum_d a[t + m][d] * b[t][d] - self_weight * Q[t - t0][m]
+// (Q may be null).  a, b are [n_frames][k].
+template <typename T>
+struct DistinctProduct {
+  const T *a, *b;
+  int k;
+  double cross_weight;
+  const double *Q;
+  int64_t t0;
+  int R;
+  double self_weight;
+  __device__ __forceinline__ double operator()(int64_t t, int m) const {
+    const T *pa = a + (t + m) * k;
+    const T *pb = b + t * k;
+    double sum = 0.0;
+    for (int d = 0; d < k; ++d)
+      sum = fma(static_cast<double>(pa[d]), static_cast<double>(pb[d]), sum);
+    sum = sum * cross_weight;
+    if (Q != nullptr) sum = sum - self_weight * Q[(t - t0) * R + m];
+    return sum;
+  }
+};
+
 // Q[0][e] = sum_chunks Q[chunk][e], planes in index order.
 __global__ __launch_bounds__(kThreads) void band_combine_kernel(double *__restrict__ Q,
                                                                 int n_chunks, int64_t plane) {
@@ -321,9 +345,9 @@ __global__ __launch_bounds__(kThreads) void band_combine_kernel(double *__restri
 template <typename Product, int kBlock>
 __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
     Product prod, int64_t ct, int64_t win_begin, int64_t n_win, int64_t windows_per_block,
-    int R, double scale, double integral_scale, const double *__restrict__ time,
-    int64_t block_offset, double *__restrict__ acf_blk, double *__restrict__ mean_blk,
-    double *__restrict__ m2_blk) {
+    int R, double scale, int lag_normalise, double integral_scale,
+    const double *__restrict__ time, int64_t block_offset, double *__restrict__ acf_blk,
+    double *__restrict__ mean_blk, double *__restrict__ m2_blk) {
   // A thread owns the lags m = tid + j * kBlock and the integral indices
   // i0 + j, j < kSlidePer; their running values stay in registers.  LDS holds two
   // images of the window correlation (so one barrier per window separates writers
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
     norm[j] = 0.0;
     dt[j] = 0.0;
     if (m < R) {
-      norm[j] = scale / static_cast<double>(R - m);
+      norm[j] = lag_normalise ? scale / static_cast<double>(R - m) : scale;
       double sum = 0.0;
       for (int n = 0; n < R - m; ++n) sum = sum + prod(o0 + n, m);
       W[j] = sum;
@@ -621,58 +645,47 @@ int windows_per_block(int64_t ct, int D, int k, int64_t n_win, int cap, size_t b
   return static_cast<int>(wpb);
 }
 
-}  // namespace
+// Inputs of the sliding-window path.  `series` [n_series][n_frames][k] feeds the lag
+// products directly (band == false) or through the band table (band == true; may be
+// null with cross_a set and no self term).  With cross_a / cross_b set the products
+// are cross_weight * a[t+m].b[t] - self_weight * (band table of `series`).
+struct SlideJob {
+  int dtype = MDX_F64;
+  const void *series = nullptr;
+  int64_t n_series = 0, n_frames = 0;
+  int k = 3;
+  int64_t ct = 1, win_begin = 0, n_win = 0;
+  int R = 0;
+  double scale = 1.0, integral_scale = 1.0;
+  const double *d_time = nullptr;
+  bool band = false;
+  bool lag_normalise = true;
+  const void *cross_a = nullptr, *cross_b = nullptr;
+  double cross_weight = 1.0, self_weight = 0.0;
+};
 
-extern "C" {
-
-int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
-                    int64_t n_frames, int k, int64_t correlation_time, int64_t win_begin,
-                    int64_t win_end, const int32_t *tau, int n_tau, double scale,
-                    double integral_scale, const double *time, double *acf_sum,
-                    double *integral_mean, double *integral_m2, int64_t *n_windows) {
-  TauInfo ti;
-  MDX_TRY(check_windows(x, dtype, location, n_series, n_frames, k, correlation_time,
-                        win_begin, win_end, tau, n_tau, &ti));
-  MDX_REQUIRE(acf_sum != nullptr, "acf_sum is null");
-  const bool want_integral = (time != nullptr);
-  if (want_integral)
-    MDX_REQUIRE(integral_mean != nullptr && integral_m2 != nullptr,
-                "integral outputs are null");
-  const int R = n_tau;
-  const int64_t n_win = win_end - win_begin;
-  if (n_windows) *n_windows = n_win;
-  if (want_integral) {
-    for (int i = 0; i + 1 < R; ++i) {
-      integral_mean[i] = 0.0;
-      integral_m2[i] = 0.0;
-    }
-  }
-  if (n_win == 0) return MDX_OK;
-
-  hipStream_t stream;
-  MDX_TRY(get_stream(&stream));
-  DeviceBuffer x_staged, d_tau, d_time, d_C, d_acf, d_mean, d_m2;
-  const void *dx = nullptr;
-  MDX_TRY(to_device(x, location,
-                    static_cast<size_t>(n_series) * n_frames * k * dtype_size(dtype), x_staged,
-                    stream, &dx));
-  MDX_TRY(d_tau.alloc(sizeof(int32_t) * R));
-  MDX_HIP(hipMemcpyAsync(d_tau.ptr, tau, sizeof(int32_t) * R, hipMemcpyHostToDevice, stream));
-  if (want_integral) {
-    MDX_TRY(d_time.alloc(sizeof(double) * R));
-    MDX_HIP(hipMemcpyAsync(d_time.ptr, time, sizeof(double) * R, hipMemcpyHostToDevice, stream));
-  }
-
-  // per-block results of whichever path runs; block_windows[b] = windows of block b
-  std::vector<int64_t> block_windows;
+// Runs acf_slide_kernel over the job's windows (in segments when a band table is
+// needed); per-block results land in d_acf / d_mean / d_m2, block_windows gets the
+// number of windows of every block.
+int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
+                  DeviceBuffer &d_acf, DeviceBuffer &d_mean, DeviceBuffer &d_m2,
+                  std::vector<int64_t> &block_windows) {
+  const int dtype = job.dtype;
+  const void *dx = job.series;
+  const int64_t n_series = job.n_series, n_frames = job.n_frames;
+  const int k = job.k;
+  const int64_t correlation_time = job.ct, win_begin = job.win_begin, n_win = job.n_win;
+  const int R = job.R;
+  const double scale = job.scale, integral_scale = job.integral_scale;
+  const int lag_normalise = job.lag_normalise ? 1 : 0;
   const int n_int = R > 1 ? R - 1 : 1;
-  const bool slide = ti.identity && R >= 2 && 4 * correlation_time <= R;
-  if (slide) {
+  const bool band = job.band;
+  const bool cross = job.cross_a != nullptr;
+  {
     // four lags per thread at most before the block grows to 1024 threads
     const int slide_block = (R > 1024) ? 1024 : 256;
     const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + slide_block / 64);
     static_assert(8192 <= kSlidePer * 1024, "lags per thread");
-    const bool band = n_series > 8;
     // windows per block: enough to amortise the directly computed first window
     // (R/2 products per lag against 2*ct per slide), few enough to fill the chip
     // and to bound the drift of the running sums
@@ -725,7 +738,7 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
     MDX_TRY(d_m2.alloc(sizeof(double) * total_blocks * n_int));
     const int64_t seg_frames = (seg_windows - 1) * correlation_time + R;
     if (band) MDX_TRY(d_C.alloc(sizeof(double) * n_chunks * seg_frames * R));
-    const double *d_time_ptr = want_integral ? d_time.as<double>() : nullptr;
+    const double *d_time_ptr = job.d_time;
 
     int64_t block_offset = 0;
     for (int64_t ws = 0; ws < n_win; ws += seg_windows) {
@@ -776,8 +789,8 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
     hipLaunchKernelGGL((acf_slide_kernel<PRODUCT_TYPE, BLOCK>),                              \
                        dim3(static_cast<unsigned>(n_blocks)), dim3(BLOCK), lds_s, stream,    \
                        PRODUCT, correlation_time, win_begin + ws, nw, wpb, R, scale,         \
-                       integral_scale, d_time_ptr, block_offset, d_acf.as<double>(),         \
-                       d_mean.as<double>(), d_m2.as<double>());                              \
+                       lag_normalise, integral_scale, d_time_ptr, block_offset,              \
+                       d_acf.as<double>(), d_mean.as<double>(), d_m2.as<double>());          \
   } while (0)
 #define MDX_LAUNCH_SLIDE(PRODUCT_TYPE, PRODUCT)                                              \
   do {                                                                                       \
@@ -803,7 +816,21 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
       MDX_LAUNCH_SLIDE(P, prod);                                                             \
     }                                                                                        \
   } while (0)
-      if (band) {
+      if (cross) {
+        const double *table = band ? d_C.as<double>() : nullptr;
+        if (dtype == MDX_F32) {
+          using P = DistinctProduct<float>;
+          P prod{static_cast<const float *>(job.cross_a), static_cast<const float *>(job.cross_b),
+                 k, job.cross_weight, table, t0, R, job.self_weight};
+          MDX_LAUNCH_SLIDE(P, prod);
+        } else {
+          using P = DistinctProduct<double>;
+          P prod{static_cast<const double *>(job.cross_a),
+                 static_cast<const double *>(job.cross_b), k, job.cross_weight, table, t0, R,
+                 job.self_weight};
+          MDX_LAUNCH_SLIDE(P, prod);
+        }
+      } else if (band) {
         BandProduct prod{d_C.as<double>(), t0, R};
         MDX_LAUNCH_SLIDE(BandProduct, prod);
       } else if (dtype == MDX_F32) {
@@ -817,6 +844,106 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
       MDX_HIP(hipGetLastError());
       block_offset += n_blocks;
     }
+  }
+  return MDX_OK;
+}
+
+// Merges the per-block results on the device (out = [acf R | mean R-1 | M2 R-1]) and
+// adds / stores them into the caller's arrays.
+int merge_blocks(hipStream_t stream, DeviceBuffer &d_acf, DeviceBuffer &d_mean,
+                 DeviceBuffer &d_m2, const std::vector<int64_t> &block_windows, int R,
+                 bool merge_moments, double *acf_sum, double *integral_mean,
+                 double *integral_m2) {
+  const int64_t n_blocks_b = static_cast<int64_t>(block_windows.size());
+  const int n_int = R > 1 ? R - 1 : 1;
+  DeviceBuffer d_counts, d_out;
+  MDX_TRY(d_counts.alloc(sizeof(int64_t) * n_blocks_b));
+  MDX_HIP(hipMemcpyAsync(d_counts.ptr, block_windows.data(), sizeof(int64_t) * n_blocks_b,
+                         hipMemcpyHostToDevice, stream));
+  MDX_TRY(d_out.alloc(sizeof(double) * (static_cast<size_t>(R) + 2 * n_int)));
+  hipLaunchKernelGGL(acf_merge_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(R, kThreads / 64))), dim3(kThreads),
+                     0, stream, d_acf.as<double>(),
+                     merge_moments ? d_mean.as<double>() : nullptr,
+                     merge_moments ? d_m2.as<double>() : nullptr, d_counts.as<int64_t>(),
+                     n_blocks_b, R, d_out.as<double>());
+  MDX_HIP(hipGetLastError());
+  std::vector<double> h_out(static_cast<size_t>(R) + 2 * n_int);
+  MDX_HIP(hipMemcpyAsync(h_out.data(), d_out.ptr, sizeof(double) * h_out.size(),
+                         hipMemcpyDeviceToHost, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  for (int m = 0; m < R; ++m) acf_sum[m] += h_out[m];
+  if (merge_moments) {
+    for (int i = 0; i < R - 1; ++i) {
+      integral_mean[i] = h_out[R + i];
+      integral_m2[i] = h_out[R + (R - 1) + i];
+    }
+  }
+  return MDX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
+                    int64_t n_frames, int k, int64_t correlation_time, int64_t win_begin,
+                    int64_t win_end, const int32_t *tau, int n_tau, double scale,
+                    double integral_scale, const double *time, double *acf_sum,
+                    double *integral_mean, double *integral_m2, int64_t *n_windows) {
+  TauInfo ti;
+  MDX_TRY(check_windows(x, dtype, location, n_series, n_frames, k, correlation_time,
+                        win_begin, win_end, tau, n_tau, &ti));
+  MDX_REQUIRE(acf_sum != nullptr, "acf_sum is null");
+  const bool want_integral = (time != nullptr);
+  if (want_integral)
+    MDX_REQUIRE(integral_mean != nullptr && integral_m2 != nullptr,
+                "integral outputs are null");
+  const int R = n_tau;
+  const int64_t n_win = win_end - win_begin;
+  if (n_windows) *n_windows = n_win;
+  if (want_integral) {
+    for (int i = 0; i + 1 < R; ++i) {
+      integral_mean[i] = 0.0;
+      integral_m2[i] = 0.0;
+    }
+  }
+  if (n_win == 0) return MDX_OK;
+
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  DeviceBuffer x_staged, d_tau, d_time, d_C, d_acf, d_mean, d_m2;
+  const void *dx = nullptr;
+  MDX_TRY(to_device(x, location,
+                    static_cast<size_t>(n_series) * n_frames * k * dtype_size(dtype), x_staged,
+                    stream, &dx));
+  MDX_TRY(d_tau.alloc(sizeof(int32_t) * R));
+  MDX_HIP(hipMemcpyAsync(d_tau.ptr, tau, sizeof(int32_t) * R, hipMemcpyHostToDevice, stream));
+  if (want_integral) {
+    MDX_TRY(d_time.alloc(sizeof(double) * R));
+    MDX_HIP(hipMemcpyAsync(d_time.ptr, time, sizeof(double) * R, hipMemcpyHostToDevice, stream));
+  }
+
+  // per-block results of whichever path runs; block_windows[b] = windows of block b
+  std::vector<int64_t> block_windows;
+  const int n_int = R > 1 ? R - 1 : 1;
+  const bool slide = ti.identity && R >= 2 && 4 * correlation_time <= R;
+  if (slide) {
+    SlideJob job;
+    job.dtype = dtype;
+    job.series = dx;
+    job.n_series = n_series;
+    job.n_frames = n_frames;
+    job.k = k;
+    job.ct = correlation_time;
+    job.win_begin = win_begin;
+    job.n_win = n_win;
+    job.R = R;
+    job.scale = scale;
+    job.integral_scale = integral_scale;
+    job.d_time = want_integral ? d_time.as<double>() : nullptr;
+    job.band = n_series > 8;
+    MDX_TRY(slide_windows(job, stream, d_C, d_acf, d_mean, d_m2, block_windows));
   } else {
     // stage A geometry
     const int n_pairs = (R + 1) / 2;
@@ -891,34 +1018,80 @@ int mdx_acf_windows(const void *x, int dtype, int location, int64_t n_series,
     for (int64_t b = 0; b < n_blocks_b; ++b)
       block_windows.push_back(std::min(wins_per_block_b, n_win - b * wins_per_block_b));
   }
-  const int64_t n_blocks_b = static_cast<int64_t>(block_windows.size());
+  return merge_blocks(stream, d_acf, d_mean, d_m2, block_windows, R, want_integral && R > 1,
+                      acf_sum, integral_mean, integral_m2);
+}
 
-  // merge the per-block results on the device: out = [acf R | mean R-1 | M2 R-1]
-  DeviceBuffer d_counts, d_out;
-  MDX_TRY(d_counts.alloc(sizeof(int64_t) * n_blocks_b));
-  MDX_HIP(hipMemcpyAsync(d_counts.ptr, block_windows.data(), sizeof(int64_t) * n_blocks_b,
-                         hipMemcpyHostToDevice, stream));
-  const bool merge_moments = want_integral && R > 1;
-  MDX_TRY(d_out.alloc(sizeof(double) * (static_cast<size_t>(R) + 2 * n_int)));
-  hipLaunchKernelGGL(acf_merge_kernel,
-                     dim3(static_cast<unsigned>(ceil_div(R, kThreads / 64))), dim3(kThreads),
-                     0, stream, d_acf.as<double>(),
-                     merge_moments ? d_mean.as<double>() : nullptr,
-                     merge_moments ? d_m2.as<double>() : nullptr, d_counts.as<int64_t>(),
-                     n_blocks_b, R, d_out.as<double>());
-  MDX_HIP(hipGetLastError());
-  std::vector<double> h_out(static_cast<size_t>(R) + 2 * n_int);
-  MDX_HIP(hipMemcpyAsync(h_out.data(), d_out.ptr, sizeof(double) * h_out.size(),
-                         hipMemcpyDeviceToHost, stream));
-  MDX_HIP(hipStreamSynchronize(stream));
-  for (int m = 0; m < R; ++m) acf_sum[m] += h_out[m];
-  if (merge_moments) {
-    for (int i = 0; i < R - 1; ++i) {
-      integral_mean[i] = h_out[R + i];
-      integral_m2[i] = h_out[R + (R - 1) + i];
+int mdx_ccf_windows(const void *a, const void *b, const void *self_atoms, int dtype,
+                    int location, int64_t n_self_atoms, int64_t n_frames, int k,
+                    int64_t correlation_time, int64_t win_begin, int64_t win_end,
+                    int data_range, double cross_weight, double self_weight,
+                    const double *time, double *cf_sum, double *integral_mean,
+                    double *integral_m2, int64_t *n_windows) {
+  MDX_REQUIRE(a != nullptr && b != nullptr && cf_sum != nullptr, "null argument");
+  MDX_REQUIRE(dtype == MDX_F32 || dtype == MDX_F64, "dtype must be MDX_F32 or MDX_F64");
+  MDX_REQUIRE(location == MDX_HOST || location == MDX_DEVICE, "bad location");
+  MDX_REQUIRE(n_frames >= 1 && k >= 1 && k <= 16, "bad series shape");
+  MDX_REQUIRE(correlation_time >= 1, "correlation_time must be >= 1");
+  MDX_REQUIRE(data_range >= 2 && data_range <= 8192, "data_range out of range (2..8192)");
+  MDX_REQUIRE(win_begin >= 0 && win_end >= win_begin, "bad window range");
+  MDX_REQUIRE(self_atoms == nullptr || n_self_atoms >= 1, "empty self term");
+  const int R = data_range;
+  const int64_t n_win = win_end - win_begin;
+  if (n_win > 0) {
+    const int64_t last = (win_end - 1) * correlation_time + R;
+    MDX_REQUIRE(last <= n_frames,
+                "window %lld needs frames up to %lld but the batch holds %lld",
+                (long long)(win_end - 1), (long long)last, (long long)n_frames);
+  }
+  const bool want_integral = (time != nullptr);
+  if (want_integral) {
+    MDX_REQUIRE(integral_mean != nullptr && integral_m2 != nullptr,
+                "integral outputs are null");
+    for (int i = 0; i + 1 < R; ++i) {
+      integral_mean[i] = 0.0;
+      integral_m2[i] = 0.0;
     }
   }
-  return MDX_OK;
+  if (n_windows) *n_windows = n_win;
+  if (n_win == 0) return MDX_OK;
+
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  DeviceBuffer a_staged, b_staged, x_staged, d_time, d_C, d_acf, d_mean, d_m2;
+  const size_t series_bytes = static_cast<size_t>(n_frames) * k * dtype_size(dtype);
+  SlideJob job;
+  MDX_TRY(to_device(a, location, series_bytes, a_staged, stream, &job.cross_a));
+  if (b == a) {
+    job.cross_b = job.cross_a;
+  } else {
+    MDX_TRY(to_device(b, location, series_bytes, b_staged, stream, &job.cross_b));
+  }
+  if (self_atoms != nullptr) {
+    MDX_TRY(to_device(self_atoms, location, series_bytes * n_self_atoms, x_staged, stream,
+                      &job.series));
+    job.n_series = n_self_atoms;
+    job.band = true;
+  }
+  if (want_integral) {
+    MDX_TRY(d_time.alloc(sizeof(double) * R));
+    MDX_HIP(hipMemcpyAsync(d_time.ptr, time, sizeof(double) * R, hipMemcpyHostToDevice, stream));
+    job.d_time = d_time.as<double>();
+  }
+  job.dtype = dtype;
+  job.n_frames = n_frames;
+  job.k = k;
+  job.ct = correlation_time;
+  job.win_begin = win_begin;
+  job.n_win = n_win;
+  job.R = R;
+  job.lag_normalise = false;
+  job.cross_weight = cross_weight;
+  job.self_weight = self_weight;
+  std::vector<int64_t> block_windows;
+  MDX_TRY(slide_windows(job, stream, d_C, d_acf, d_mean, d_m2, block_windows));
+  return merge_blocks(stream, d_acf, d_mean, d_m2, block_windows, R, want_integral, cf_sum,
+                      integral_mean, integral_m2);
 }
 
 int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,

@@ -443,6 +443,53 @@ def acf_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: in
     return acf, moments
 
 
+def ccf_windows(a: ArrayLike, b: ArrayLike, correlation_time: int, win_begin: int,
+                win_end: int, data_range: int, cross_weight: float = 1.0,
+                self_atoms: Optional[ArrayLike] = None, self_weight: float = 0.0,
+                time: Optional[np.ndarray] = None):
+    """Windowed cross-correlation of the series ``a``, ``b`` ``[T, k]`` minus
+    ``self_weight`` times the summed autocorrelation of ``self_atoms`` ``[N, T, k]``,
+    without lag normalisation; see ``mdx_ccf_windows``.  Returns ``(cf_sum, moments)``."""
+    infos = [_as_input(a)]
+    infos.append(infos[0] if b is a else _as_input(b))
+    if self_atoms is not None:
+        infos.append(_as_input(self_atoms))
+    if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
+        raise ValueError("all inputs must share dtype and location")
+    shape = tuple(infos[0][3])
+    if len(shape) != 2 or tuple(infos[1][3]) != shape:
+        raise ValueError("a and b must both have shape (n_frames, k)")
+    n_self, sptr = 0, None
+    if self_atoms is not None:
+        sshape = tuple(infos[2][3])
+        if len(sshape) != 3 or sshape[1:] != shape:
+            raise ValueError("self_atoms must have shape (n_atoms, n_frames, k)")
+        n_self, sptr = sshape[0], infos[2][0]
+    R = int(data_range)
+    cf = np.zeros(R, dtype=np.float64)
+    n_win = ctypes.c_int64(0)
+    if time is not None:
+        time_arr = np.ascontiguousarray(time, dtype=np.float64)
+        if time_arr.shape != (R,):
+            raise ValueError("time must have one entry per lag")
+        mean = np.zeros(max(R - 1, 1), dtype=np.float64)
+        m2 = np.zeros(max(R - 1, 1), dtype=np.float64)
+        tptr = time_arr.ctypes.data_as(_lib.c_f64_p)
+        mptr = mean.ctypes.data_as(_lib.c_f64_p)
+        m2ptr = m2.ctypes.data_as(_lib.c_f64_p)
+    else:
+        tptr = mptr = m2ptr = None
+    check(_lib.load().mdx_ccf_windows(
+        infos[0][0], infos[1][0], sptr, infos[0][1], infos[0][2], n_self, shape[0], shape[1],
+        int(correlation_time), int(win_begin), int(win_end), R, float(cross_weight),
+        float(self_weight), tptr, cf.ctypes.data_as(_lib.c_f64_p), mptr, m2ptr,
+        ctypes.byref(n_win)))
+    moments = None
+    if time is not None:
+        moments = Moments(int(n_win.value), mean[:R - 1], m2[:R - 1])
+    return cf, moments
+
+
 def msd_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: int, tau,
                 scale: float = 1.0) -> np.ndarray:
     """Windowed squared displacement sums of ``x`` ``[S, T, k]``; see ``mdx_msd_windows``."""

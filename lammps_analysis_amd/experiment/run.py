@@ -118,5 +118,13 @@ class RunComputation:
         return self._calculator("EinsteinDiffusionCoefficients")
 
     @property
+    def EinsteinDistinctDiffusionCoefficients(self):
+        return self._calculator("EinsteinDistinctDiffusionCoefficients")
+
+    @property
+    def GreenKuboDistinctDiffusionCoefficients(self):
+        return self._calculator("GreenKuboDistinctDiffusionCoefficients")
+
+    @property
     def EinsteinHelfandIonicConductivity(self):
         return self._calculator("EinsteinHelfandIonicConductivity")

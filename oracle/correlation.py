@@ -430,3 +430,71 @@ def green_kubo_windowed_flux(series: np.ndarray, data_range: int, correlation_ti
         trapezoid = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
         sigma.append(trapezoid(jacf[:integration_range], x=time[:integration_range]))
     return jacf_sum, np.array(sigma)
+
+
+# --------------------------------------------------------- distinct diffusion
+
+def correlate(ds_a: np.ndarray, ds_b: np.ndarray) -> np.ndarray:
+    """mdsuite/utils/calculator_helper_methods.py:110-148: ``jnp.correlate(a, b,
+    "full")`` per dimension, mean over dimensions, lags ``0..T-1``; float64 here
+    (the reference runs JAX at its float32 default)."""
+    ds_a = np.asarray(ds_a, dtype=np.float64)
+    ds_b = np.asarray(ds_b, dtype=np.float64)
+    per_dim = [np.correlate(ds_a[:, d], ds_b[:, d], mode="full") for d in range(ds_a.shape[1])]
+    acf = np.mean(per_dim, axis=0)
+    return acf[int(len(acf) / 2):]
+
+
+def msd_operation(ds_a: np.ndarray, ds_b: np.ndarray) -> np.ndarray:
+    """mdsuite/utils/calculator_helper_methods.py:153-184."""
+    ds_a = np.asarray(ds_a, dtype=np.float64)
+    ds_b = np.asarray(ds_b, dtype=np.float64)
+    return np.mean((ds_a - ds_a[0]) * (ds_b - ds_b[0]), axis=-1)
+
+
+def map_over_particles(ds_a: np.ndarray, ds_b: np.ndarray, op) -> np.ndarray:
+    """``_map_over_particles`` of both distinct calculators
+    (green_kubo_distinct_diffusion_coefficients.py:192-238): mean over all (i, j) of
+    ``op(a_i, b_j)``, literally as the double loop."""
+    acc = None
+    for a_i in ds_a:
+        inner = np.mean([op(a_i, b_j) for b_j in ds_b], axis=0)
+        acc = inner if acc is None else acc + inner
+    return acc / len(ds_a)
+
+
+def green_kubo_distinct_windows(vel_a: np.ndarray, vel_b: np.ndarray, same_species: bool,
+                                data_range: int, correlation_time: int, time: np.ndarray):
+    """Ensemble loop of GreenKuboDistinctDiffusionCoefficients over one batch
+    (:240-290): returns (sum of window vacfs, list of trapezoid integrals)."""
+    vel_a = np.asarray(vel_a, dtype=np.float64)
+    vel_b = np.asarray(vel_b, dtype=np.float64)
+    vacf_sum = np.zeros(data_range)
+    sigma = []
+    for start in window_starts(vel_a.shape[1], data_range, correlation_time):
+        win_a = vel_a[:, start:start + data_range]
+        win_b = vel_b[:, start:start + data_range]
+        vacf = map_over_particles(win_a, win_b, correlate)
+        if same_species:
+            vacf = vacf - np.mean([correlate(x, y) for x, y in zip(win_a, win_b)], axis=0)
+        vacf_sum += vacf
+        sigma.append(np.trapezoid(vacf, x=time) if hasattr(np, "trapezoid")
+                     else np.trapz(vacf, x=time))
+    return vacf_sum, sigma
+
+
+def einstein_distinct_windows(pos_a: np.ndarray, pos_b: np.ndarray, same_species: bool,
+                              data_range: int, correlation_time: int) -> np.ndarray:
+    """Ensemble loop of EinsteinDistinctDiffusionCoefficients over one batch
+    (einstein_distinct_diffusion_coefficients.py:174-262): sum of the window msds."""
+    pos_a = np.asarray(pos_a, dtype=np.float64)
+    pos_b = np.asarray(pos_b, dtype=np.float64)
+    msd_sum = np.zeros(data_range)
+    for start in window_starts(pos_a.shape[1], data_range, correlation_time):
+        win_a = pos_a[:, start:start + data_range]
+        win_b = pos_b[:, start:start + data_range]
+        msd = map_over_particles(win_a, win_b, msd_operation)
+        if same_species:
+            msd = msd - np.mean([msd_operation(x, y) for x, y in zip(win_a, win_b)], axis=0)
+        msd_sum += msd
+    return msd_sum
