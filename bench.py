@@ -201,8 +201,17 @@ def main() -> None:
                  "is f32 VALU issue + LDS atomics, see valu"),
     }
     pairs_per_s_kernel = pairs_per_frame * frames_per_launch / (tile_avg_ms * 1e-3)
+    # VALU issue bound of the table kernel's wrapped-frame loop: 17.5 issue slots per
+    # pair (ISA count: 1.5 packed subtract, 6 minimum image, 2.5 packed square/add,
+    # 2 for the 8-cycle v_sqrt_f32, 0.5 packed fma, 5 cutoff/bin/edge/address), one
+    # slot = 4 cycles of a SIMD16 for a 64-lane wave, 1024 SIMDs at 2.4 GHz
+    slots_per_pair = 17.5
+    issue_bound = 1024 * 2.4e9 / 4.0 * 64 / slots_per_pair
     valu = {
         "pairs_per_s_kernel": pairs_per_s_kernel,
+        "issue_slots_per_pair": slots_per_pair,
+        "issue_bound_pairs_per_s": issue_bound,
+        "frac_of_issue_bound": pairs_per_s_kernel / issue_bound,
         "pairs_per_s_end_to_end": pairs_per_frame * value / world,
         "pack_kernel_ms_total": pack_ms,
         "tile_kernel_ms_total": tile_ms,
