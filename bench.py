@@ -395,6 +395,36 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "band_kernel_tflops_f64": band_flops / (band_avg * 1e-3) / 1e12 if band_avg else None,
         "f64_vector_peak_tflops": 78.6,
     }
+    # per-atom mean-square displacement of one species (EinsteinDiffusionCoefficients,
+    # default data_range 100), on the same array read as positions
+    msd_range = 100
+    tau_msd = np.arange(msd_range)
+
+    def msd():
+        return engine.msd_windows(vel_na, 1, 0, n_frames - msd_range, tau_msd)
+
+    msd()  # warm-up
+    engine.profile_enable(True)
+    engine.profile_reset()
+    engine.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        msd()
+    engine.synchronize()
+    dt_m = (time.perf_counter() - t0) / reps
+    engine.profile_enable(False)
+    msd_ms, msd_n = engine.profile_query("msd")
+    msd_avg = msd_ms / max(msd_n, 1)
+    out["einstein_msd"] = {
+        "workload": f"per-atom MSD, {N_NA} atoms x {n_frames} frames, data_range {msd_range}, "
+                    "correlation_time 1",
+        "frames_per_s": n_frames / dt_m,
+        "ms_per_pass": dt_m * 1e3,
+        "band_kernel_ms": msd_avg,
+        # subtract + fma per origin, lag, atom and component
+        "band_kernel_tflops_f64": (3.0 * n_frames * msd_range * N_NA * 3
+                                   / (msd_avg * 1e-3) / 1e12) if msd_avg else None,
+    }
     vel_na.free()
     vel_cl.free()
     return out

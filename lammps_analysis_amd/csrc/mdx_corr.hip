@@ -438,36 +438,50 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
   }
 }
 
-// Band table Q[chunk][t][m] = sum_{s in chunk} sum_d x_s[t0 + t][d] * x_s[t0 + t + m][d]
-// for t < t_len, m < R.  A block owns a tile of kBandT frames x kBandM lags and a
-// chunk of series; a thread owns an 8 x 8 patch of it, whose 64 products per
-// dimension need only 8 + 15 staged values because x_s[t + m] depends on t + m.
-// The frames of one series are staged per dimension with one pad slot after
-// every 8 frames, which spreads the 8-frame lane stride over all LDS banks.
-constexpr int kBandT = 64;
-constexpr int kBandM = 256;
-constexpr int kBandSpan = kBandT + kBandM;  // frames t + m a tile touches
-
+// Band kernel.  For frames t (relative to t0) and lags m, summed over a chunk of series:
+//   kMsd == false   Q[chunk][t][m] = sum_s sum_d x_s[t][d] * x_s[t + m][d]     (t < t_len, m < R)
+//   kMsd == true    partial[chunk * tiles_t + tile][m] = sum_{t in tile, t < t_len}
+//                                           sum_s sum_d (x_s[t + m][d] - x_s[t][d])^2
+// A block owns a tile of 8*TG frames x 8*MG lags (TG * MG = 256 threads) and a chunk of
+// series; a thread owns an 8 x 8 patch of it, whose 64 terms per dimension need only
+// 8 + 15 staged values because x_s[t + m] depends on t + m.  The frames of one series
+// are staged per dimension with one pad slot after every 8 frames, which spreads the
+// 8-frame lane stride over all LDS banks.
 // K = number of components when known at compile time (the next series is then
-// fetched into registers while the current one is being multiplied), 0 otherwise.
-template <typename T, int K>
+// fetched into registers while the current one is being processed), 0 otherwise.
+template <int MG>
+struct BandTile {
+  static constexpr int TG = kThreads / MG;
+  static constexpr int T = 8 * TG;      // frames per tile
+  static constexpr int M = 8 * MG;      // lags per tile
+  static constexpr int kStage = T + (T + M);  // staged frames: x[t], then x[t + m]
+  static constexpr int kPitch = kStage + kStage / 8;
+  static size_t lds_bytes(int k) {
+    const size_t image = sizeof(double) * 2 * k * kPitch;
+    const size_t reduce = sizeof(double) * TG * M;
+    return image > reduce ? image : reduce;
+  }
+};
+
+template <typename T, int K, int MG, bool kMsd>
 __global__ __launch_bounds__(kThreads) void acf_band_kernel(
     const T *__restrict__ x, int64_t n_series, int64_t n_frames, int k_runtime, int64_t t0,
     int64_t t_len, int R, int64_t series_per_chunk, double *__restrict__ Q) {
+  using Tile = BandTile<MG>;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *img = reinterpret_cast<double *>(lds_raw);  // [2][k][pitch]
   const int k = (K > 0) ? K : k_runtime;
-  const int mg = threadIdx.x & 31;
-  const int tg = threadIdx.x >> 5;
-  const int64_t tile_t = static_cast<int64_t>(blockIdx.x) * kBandT;
-  const int tile_m = blockIdx.y * kBandM;
+  const int mg = threadIdx.x % MG;
+  const int tg = threadIdx.x / MG;
+  const int64_t tile_t = static_cast<int64_t>(blockIdx.x) * Tile::T;
+  const int tile_m = blockIdx.y * Tile::M;
   const int64_t s0 = static_cast<int64_t>(blockIdx.z) * series_per_chunk;
   const int64_t s1 = min(n_series, s0 + series_per_chunk);
-  // staged per series: the tile's kBandT frames x[t] first, then the kBandSpan
-  // frames x[t + m] starting at frame0
+  // staged per series: the tile's frames x[t] first, then the T + M frames x[t + m]
+  // starting at frame0
   const int64_t frame0 = t0 + tile_t + tile_m;
-  constexpr int n_stage = kBandT + kBandSpan;
-  constexpr int pitch = n_stage + n_stage / 8;
+  constexpr int n_stage = Tile::kStage;
+  constexpr int pitch = Tile::kPitch;
   constexpr int kOwn = (n_stage + kThreads - 1) / kThreads;  // frames a thread stages
   const int plane = k * pitch;
 
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(kThreads) void acf_band_kernel(
 #pragma unroll
   for (int o = 0; o < kOwn; ++o) {
     const int f = threadIdx.x + o * kThreads;
-    const int64_t frame = (f < kBandT) ? (t0 + tile_t + f) : (frame0 + (f - kBandT));
+    const int64_t frame = (f < Tile::T) ? (t0 + tile_t + f) : (frame0 + (f - Tile::T));
     own_frame[o] = (f < n_stage && frame < n_frames) ? frame : -1;
     own_slot[o] = (f < n_stage) ? f + (f >> 3) : -1;
   }
@@ -526,26 +540,55 @@ __global__ __launch_bounds__(kThreads) void acf_band_kernel(
       double a[8], b[15];
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i] = row[9 * tg + i];
-      const double *rb = row + (kBandT + kBandT / 8) + 9 * (tg + mg);
+      const double *rb = row + (Tile::T + Tile::T / 8) + 9 * (tg + mg);
 #pragma unroll
       for (int c = 0; c < 15; ++c) b[c] = rb[c + (c >> 3)];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = fma(a[i], b[i + j], acc[i][j]);
+        for (int j = 0; j < 8; ++j) {
+          if (kMsd) {
+            const double diff = b[i + j] - a[i];
+            acc[i][j] = fma(diff, diff, acc[i][j]);
+          } else {
+            acc[i][j] = fma(a[i], b[i + j], acc[i][j]);
+          }
+        }
     }
     buf ^= 1;  // the other image was last read before this iteration's barrier
   }
-  double *out = Q + static_cast<int64_t>(blockIdx.z) * t_len * R;
+  if (!kMsd) {
+    double *out = Q + static_cast<int64_t>(blockIdx.z) * t_len * R;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t t = tile_t + 8 * tg + i;
-    if (t >= t_len) continue;
+    for (int i = 0; i < 8; ++i) {
+      const int64_t t = tile_t + 8 * tg + i;
+      if (t >= t_len) continue;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = tile_m + 8 * mg + j;
-      if (m < R) out[t * R + m] = acc[i][j];
+      for (int j = 0; j < 8; ++j) {
+        const int m = tile_m + 8 * mg + j;
+        if (m < R) out[t * R + m] = acc[i][j];
+      }
     }
+    return;
+  }
+  // sum over the tile's frames: first this thread's 8, then the TG thread groups
+  __syncthreads();  // the staged images are no longer read
+  double *red = img;  // [TG][M]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (tile_t + 8 * tg + i < t_len) sum = sum + acc[i][j];
+    red[tg * Tile::M + 8 * mg + j] = sum;
+  }
+  __syncthreads();
+  double *out = Q + (static_cast<int64_t>(blockIdx.z) * gridDim.x + blockIdx.x) * R;
+  for (int m = threadIdx.x; m < Tile::M; m += kThreads) {
+    if (tile_m + m >= R) continue;
+    double sum = 0.0;
+    for (int g = 0; g < Tile::TG; ++g) sum = sum + red[g * Tile::M + m];
+    out[tile_m + m] = sum;
   }
 }
 
@@ -708,8 +751,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
     int64_t n_chunks = 1, series_per_chunk = n_series;
     if (band) {
       // series chunks only as far as needed to fill the chip with band tiles
-      const int64_t tiles = ceil_div((n_win - 1) * correlation_time + R, kBandT) *
-                            ceil_div(R, kBandM);
+      const int64_t tiles = ceil_div((n_win - 1) * correlation_time + R, BandTile<32>::T) *
+                            ceil_div(R, BandTile<32>::M);
       n_chunks = ceil_div(2048, tiles);
       if (n_chunks > n_series / 32) n_chunks = n_series / 32;
       if (n_chunks > 16) n_chunks = 16;
@@ -750,19 +793,19 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
       const int64_t t0 = (win_begin + ws) * correlation_time;
       const int64_t t_len = (nw - 1) * correlation_time + R;
       if (band) {
-        const size_t lds_q = sizeof(double) * 2 * k *
-                             static_cast<size_t>((kBandT + kBandSpan) + (kBandT + kBandSpan) / 8);
-        dim3 grid_q(static_cast<unsigned>(ceil_div(t_len, kBandT)),
-                    static_cast<unsigned>(ceil_div(R, kBandM)), static_cast<unsigned>(n_chunks));
+        using Tile = BandTile<32>;
+        const size_t lds_q = Tile::lds_bytes(k);
+        dim3 grid_q(static_cast<unsigned>(ceil_div(t_len, Tile::T)),
+                    static_cast<unsigned>(ceil_div(R, Tile::M)), static_cast<unsigned>(n_chunks));
         KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
 #define MDX_LAUNCH_BAND(TYPE, KK)                                                            \
   do {                                                                                       \
-    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_band_kernel<TYPE, KK>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize,                  \
-                                static_cast<int>(lds_q)));                                   \
-    hipLaunchKernelGGL((acf_band_kernel<TYPE, KK>), grid_q, dim3(kThreads), lds_q, stream,   \
-                       static_cast<const TYPE *>(dx), n_series, n_frames, k, t0, t_len, R,   \
-                       series_per_chunk, d_C.as<double>());                                  \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(acf_band_kernel<TYPE, KK, 32, false>),                \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_q)));               \
+    hipLaunchKernelGGL((acf_band_kernel<TYPE, KK, 32, false>), grid_q, dim3(kThreads), lds_q, \
+                       stream, static_cast<const TYPE *>(dx), n_series, n_frames, k, t0,     \
+                       t_len, R, series_per_chunk, d_C.as<double>());                        \
   } while (0)
         if (dtype == MDX_F32) {
           if (k == 3) MDX_LAUNCH_BAND(float, 3); else MDX_LAUNCH_BAND(float, 0);
@@ -1115,6 +1158,63 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
                     stream, &dx));
   MDX_TRY(d_tau.alloc(sizeof(int32_t) * R));
   MDX_HIP(hipMemcpyAsync(d_tau.ptr, tau, sizeof(int32_t) * R, hipMemcpyHostToDevice, stream));
+
+  // Many series, consecutive origins and every lag: the band kernel evaluates the
+  // squared displacements of a tile of origins x lags from one staged image per series.
+  if (ti.identity && correlation_time == 1 && n_series >= 8 && R >= 16) {
+    const bool narrow = R <= 128;
+    const int tile_t = narrow ? BandTile<16>::T : BandTile<32>::T;
+    const int tile_m = narrow ? BandTile<16>::M : BandTile<32>::M;
+    const size_t lds_q = narrow ? BandTile<16>::lds_bytes(k) : BandTile<32>::lds_bytes(k);
+    const int64_t tiles_t = ceil_div(n_win, tile_t);
+    const int64_t tiles_m = ceil_div(R, tile_m);
+    int64_t n_chunks = ceil_div(2048, tiles_t * tiles_m);
+    if (n_chunks > n_series / 8) n_chunks = n_series / 8;
+    if (n_chunks > 65535) n_chunks = 65535;
+    if (n_chunks < 1) n_chunks = 1;
+    const int64_t series_per_chunk = ceil_div(n_series, n_chunks);
+    n_chunks = ceil_div(n_series, series_per_chunk);
+    MDX_REQUIRE(tiles_t <= 2147483647LL, "grid too large");
+    const int64_t n_blocks = tiles_t * n_chunks;
+    MDX_TRY(d_partial.alloc(sizeof(double) * n_blocks * R));
+    MDX_TRY(d_out.alloc(sizeof(double) * R));
+    dim3 grid_q(static_cast<unsigned>(tiles_t), static_cast<unsigned>(tiles_m),
+                static_cast<unsigned>(n_chunks));
+    {
+      KernelTimer timer(MDX_SLOT_MSD, stream);
+#define MDX_LAUNCH_MSD_BAND(TYPE, KK, MGG)                                                   \
+  do {                                                                                       \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(acf_band_kernel<TYPE, KK, MGG, true>),                \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_q)));               \
+    hipLaunchKernelGGL((acf_band_kernel<TYPE, KK, MGG, true>), grid_q, dim3(kThreads), lds_q, \
+                       stream, static_cast<const TYPE *>(dx), n_series, n_frames, k,         \
+                       win_begin, n_win, R, series_per_chunk, d_partial.as<double>());       \
+  } while (0)
+#define MDX_LAUNCH_MSD_BAND_K(TYPE, MGG)                                                     \
+  do {                                                                                       \
+    if (k == 3) MDX_LAUNCH_MSD_BAND(TYPE, 3, MGG); else MDX_LAUNCH_MSD_BAND(TYPE, 0, MGG);   \
+  } while (0)
+      if (dtype == MDX_F32) {
+        if (narrow) MDX_LAUNCH_MSD_BAND_K(float, 16); else MDX_LAUNCH_MSD_BAND_K(float, 32);
+      } else {
+        if (narrow) MDX_LAUNCH_MSD_BAND_K(double, 16); else MDX_LAUNCH_MSD_BAND_K(double, 32);
+      }
+#undef MDX_LAUNCH_MSD_BAND_K
+#undef MDX_LAUNCH_MSD_BAND
+    }
+    MDX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(combine_blocks_kernel,
+                       dim3(static_cast<unsigned>(ceil_div(R, kThreads))), dim3(kThreads), 0,
+                       stream, d_partial.as<double>(), n_blocks, R, scale, d_out.as<double>());
+    MDX_HIP(hipGetLastError());
+    std::vector<double> h(static_cast<size_t>(R));
+    MDX_HIP(hipMemcpyAsync(h.data(), d_out.ptr, sizeof(double) * R, hipMemcpyDeviceToHost,
+                           stream));
+    MDX_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < R; ++i) msd_sum[i] += h[i];
+    return MDX_OK;
+  }
 
   const int wpb = windows_per_block(correlation_time, ti.D, k, n_win, 256, 48 * 1024);
   const size_t lds =

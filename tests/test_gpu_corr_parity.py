@@ -219,3 +219,22 @@ def test_msd_subsampled_tau_and_scale(gpu):
     tau = np.array([0, 3, 4, 10, 49])
     got = gpu.msd_windows(pos, 2, 5, 60, tau, scale=2.5)
     assert_close(got, c_oracle.msd_windows(pos, 2, 5, 60, tau, scale=2.5))
+
+
+@pytest.mark.parametrize("S,T,D,k,begin,dtype", [
+    (20, 900, 300, 3, 0, np.float32),      # wide lag tile, ragged window and lag edges
+    (9, 500, 100, 3, 37, np.float64),      # narrow lag tile, window range with an offset
+    (12, 400, 40, 2, 0, np.float32),       # two components
+    (64, 300, 17, 1, 5, np.float64),       # scalar series, several series chunks
+])
+def test_msd_band_path_many_series(gpu, S, T, D, k, begin, dtype):
+    """Consecutive origins, every lag and at least 8 series: squared displacements of a
+    tile of origins x lags come from one staged image per series."""
+    rng = np.random.default_rng(18)
+    pos = (np.cumsum(rng.normal(size=(S, T, k)), axis=1) + 50.0).astype(dtype)
+    tau = np.arange(D)
+    end = T - D
+    got = gpu.msd_windows(pos, 1, begin, end, tau, scale=0.25)
+    assert_close(got, c_oracle.msd_windows(pos.astype(np.float64), 1, begin, end, tau,
+                                           scale=0.25), rtol=1e-10)
+    assert got[0] == 0.0
