@@ -592,6 +592,108 @@ __global__ __launch_bounds__(kThreads) void acf_band_kernel(
   }
 }
 
+// The band table of three-component series on the matrix cores.  With the rows
+// (series, component) as the inner dimension, Q[t][t + m] is the Gram matrix X^T X
+// restricted to a band, so 16 x 16 tiles of it are v_mfma_f64_16x16x4_f64 products of
+// staged frame blocks: A = the tile's own frames (one block of 16 per wave), B = the
+// frames 16 j further on.  A block owns 64 frames x 256 lags: wave w holds the 17
+// 16 x 16 tiles (frames 16w.., frames 16(w + j).., j = 0..16) that cover its lags, the
+// first and last of them half used.  Eight series (24 rows = 6 inner blocks of 4) are
+// staged per round in the input precision, double buffered, the next round
+// prefetched into registers.
+// Operand layout of the instruction (checked on gfx950): lane l supplies
+// A[l % 16][l / 16] and B[l / 16][l % 16] and receives D[l / 16 + 4 r][l % 16], r < 4.
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int kMfT = 64;
+constexpr int kMfM = 256;
+constexpr int kMfTiles = kMfM / 16 + 1;          // 16 x 16 tiles per wave
+constexpr int kMfSeries = 8;                     // series per staging round
+constexpr int kMfRows = 3 * kMfSeries;
+constexpr int kMfFrames = kMfT + (kMfT + kMfM);  // 64 own frames, then 320 shifted ones
+constexpr int kMfPerLane = kMfFrames / 64;       // frames a thread stages per series
+// row pitch: the four rows of an inner block land 16 (float) / 32 (double) banks apart
+constexpr int kMfPitch = kMfFrames + 16;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void acf_band_mfma_kernel(
+    const T *__restrict__ x, int64_t n_series, int64_t n_frames, int64_t t0, int64_t t_len,
+    int R, int64_t series_per_chunk, double *__restrict__ Q) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  // staged in the input type (converted when read): [2][kMfRows][kMfPitch]
+  T(*img)[kMfRows][kMfPitch] = reinterpret_cast<T(*)[kMfRows][kMfPitch]>(lds_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t tile_t = static_cast<int64_t>(blockIdx.x) * kMfT;
+  const int tile_m = blockIdx.y * kMfM;
+  const int64_t s0 = static_cast<int64_t>(blockIdx.z) * series_per_chunk;
+  const int64_t s1 = min(n_series, s0 + series_per_chunk);
+
+  // staging: thread = (series slots wave, wave + 4, frames lane + 64 q)
+  constexpr int kSlots = kMfSeries / 4;
+  int64_t own_frame[kMfPerLane];
+#pragma unroll
+  for (int q = 0; q < kMfPerLane; ++q) {
+    const int f = lane + 64 * q;
+    const int64_t frame = (f < kMfT) ? (t0 + tile_t + f) : (t0 + tile_t + tile_m + (f - kMfT));
+    own_frame[q] = (frame < n_frames) ? frame : -1;
+  }
+  T pre[kSlots][kMfPerLane][3];
+  auto fetch = [&](int64_t s_base) {
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) {
+      const int64_t s = s_base + wave + 4 * u;
+      const T *series = x + s * n_frames * 3;
+#pragma unroll
+      for (int q = 0; q < kMfPerLane; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          pre[u][q][d] = (s < s1 && own_frame[q] >= 0) ? series[own_frame[q] * 3 + d] : T(0);
+    }
+  };
+
+  v4d acc[kMfTiles];
+#pragma unroll
+  for (int j = 0; j < kMfTiles; ++j) acc[j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  if (s0 < s1) fetch(s0);
+  int buf = 0;
+  const int kk = lane >> 4;
+  const int col = lane & 15;
+  for (int64_t s_base = s0; s_base < s1; s_base += kMfSeries) {
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u)
+#pragma unroll
+      for (int q = 0; q < kMfPerLane; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) img[buf][(wave + 4 * u) * 3 + d][lane + 64 * q] = pre[u][q][d];
+    __syncthreads();
+    if (s_base + kMfSeries < s1) fetch(s_base + kMfSeries);
+#pragma unroll
+    for (int g = 0; g < kMfRows / 4; ++g) {
+      const T *row = img[buf][4 * g + kk];
+      const double a = static_cast<double>(row[16 * wave + col]);
+#pragma unroll
+      for (int j = 0; j < kMfTiles; ++j) {
+        const double b = static_cast<double>(row[kMfT + 16 * (wave + j) + col]);
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    buf ^= 1;  // the other image was last read before this round's barrier
+  }
+  double *out = Q + static_cast<int64_t>(blockIdx.z) * t_len * R;
+#pragma unroll
+  for (int j = 0; j < kMfTiles; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int trow = kk + 4 * r;
+      const int m_rel = 16 * j + col - trow;
+      const int64_t t = tile_t + 16 * wave + trow;
+      const int m = tile_m + m_rel;
+      if (m_rel >= 0 && m_rel < kMfM && m < R && t < t_len) out[t * R + m] = acc[j][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------ MSD
 
 // partial[block][i] = sum over the block's windows and series of
@@ -751,8 +853,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
     int64_t n_chunks = 1, series_per_chunk = n_series;
     if (band) {
       // series chunks only as far as needed to fill the chip with band tiles
-      const int64_t tiles = ceil_div((n_win - 1) * correlation_time + R, BandTile<32>::T) *
-                            ceil_div(R, BandTile<32>::M);
+      const int64_t tiles = ceil_div((n_win - 1) * correlation_time + R, kMfT) *
+                            ceil_div(R, kMfM);
       n_chunks = ceil_div(2048, tiles);
       if (n_chunks > n_series / 32) n_chunks = n_series / 32;
       if (n_chunks > 16) n_chunks = 16;
@@ -797,6 +899,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
         const size_t lds_q = Tile::lds_bytes(k);
         dim3 grid_q(static_cast<unsigned>(ceil_div(t_len, Tile::T)),
                     static_cast<unsigned>(ceil_div(R, Tile::M)), static_cast<unsigned>(n_chunks));
+        dim3 grid_mf(static_cast<unsigned>(ceil_div(t_len, kMfT)),
+                     static_cast<unsigned>(ceil_div(R, kMfM)), static_cast<unsigned>(n_chunks));
         KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
 #define MDX_LAUNCH_BAND(TYPE, KK)                                                            \
   do {                                                                                       \
@@ -807,11 +911,27 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
                        stream, static_cast<const TYPE *>(dx), n_series, n_frames, k, t0,     \
                        t_len, R, series_per_chunk, d_C.as<double>());                        \
   } while (0)
+#define MDX_LAUNCH_BAND_MFMA(TYPE)                                                           \
+  do {                                                                                       \
+    const size_t lds_mf = sizeof(TYPE) * 2 * kMfRows * kMfPitch;                             \
+    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_band_mfma_kernel<TYPE>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                static_cast<int>(lds_mf)));                                  \
+    hipLaunchKernelGGL((acf_band_mfma_kernel<TYPE>), grid_mf, dim3(kThreads), lds_mf,        \
+                       stream, static_cast<const TYPE *>(dx), n_series, n_frames, t0, t_len, \
+                       R, series_per_chunk, d_C.as<double>());                               \
+  } while (0)
+        const bool mfma = (k == 3) && getenv("MDX_ACF_BAND_VALU") == nullptr;
         if (dtype == MDX_F32) {
-          if (k == 3) MDX_LAUNCH_BAND(float, 3); else MDX_LAUNCH_BAND(float, 0);
+          if (mfma) MDX_LAUNCH_BAND_MFMA(float);
+          else if (k == 3) MDX_LAUNCH_BAND(float, 3);
+          else MDX_LAUNCH_BAND(float, 0);
         } else {
-          if (k == 3) MDX_LAUNCH_BAND(double, 3); else MDX_LAUNCH_BAND(double, 0);
+          if (mfma) MDX_LAUNCH_BAND_MFMA(double);
+          else if (k == 3) MDX_LAUNCH_BAND(double, 3);
+          else MDX_LAUNCH_BAND(double, 0);
         }
+#undef MDX_LAUNCH_BAND_MFMA
 #undef MDX_LAUNCH_BAND
         MDX_HIP(hipGetLastError());
         if (n_chunks > 1) {
