@@ -202,11 +202,11 @@ __global__ __launch_bounds__(kThreads) void acf_finish_kernel(
     for (int i = i0; i < i1; ++i)
       run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
     run = block_exclusive_scan<kThreads>(run, tot);
-    const double count = static_cast<double>(w - w0 + 1);
+    const double inv_count = 1.0 / static_cast<double>(w - w0 + 1);
     for (int i = i0; i < i1; ++i) {
       run = run + (time[i + 1] - time[i]) * (cs[i + 1] + cs[i]) / 2.0;
       const double delta = run - mean[i];
-      const double mu = mean[i] + delta / count;
+      const double mu = mean[i] + delta * inv_count;
       mean[i] = mu;
       m2[i] = m2[i] + delta * (run - mu);
     }
@@ -415,13 +415,13 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
       }
     }
     run = block_exclusive_scan<kBlock>(run, tot);
-    const double count = static_cast<double>(w - w0 + 1);
+    const double inv_count = 1.0 / static_cast<double>(w - w0 + 1);
 #pragma unroll
     for (int j = 0; j < kSlidePer; ++j) {
       if (i0 + j < i1) {
         run = run + part[j];
         const double delta = run - mean[j];
-        const double mu = mean[j] + delta / count;
+        const double mu = mean[j] + delta * inv_count;
         mean[j] = mu;
         m2[j] = m2[j] + delta * (run - mu);
       }
