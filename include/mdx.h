@@ -186,6 +186,32 @@ int mdx_thermal_flux(const void *stress, const void *vel, const void *ke,
                      int64_t n_frames, double *out, int out_location,
                      int accumulate);
 
+/* ------------------------------------------- angular distribution function */
+/*
+ * Weighted angle histograms of all atom triples, one batch of configurations of
+ * AngularDistributionFunction._build_histograms (mdsuite/calculators/
+ * angular_distribution_function.py:385-425 with get_neighbour_list / get_triplets,
+ * mdsuite/utils/neighbour_list.py:54-177, and get_angles, mdsuite/utils/linalg.py:30-81).
+ * Atoms are numbered through the species in the given order.  For every frame, every
+ * atom i and every ordered pair (j, k), j != k, of atoms whose float32 minimum-image
+ * distance to i, rounded to float16, is non-zero and below float16(cutoff):
+ *   angle  = acos(clamp(u_ij . u_ik, -1, 1)),  u = r / |r| in float32
+ *   weight = 1 / (|r_ij| * |r_ik|) ^ norm_power          (float32)
+ * is added (float64) to hist[c][bin] when the species of (i, j, k) are the c-th
+ * combination with replacement of the species list (i.e. non-decreasing species
+ * order; other orders are not counted, as in the reference); bin is the one with
+ * bin_edges[bin] <= angle < bin_edges[bin+1], the last bin closed, bin_edges having
+ * nbins + 1 entries.  triple_counts[c] receives the number of triples.  Both outputs
+ * are added to; density normalisation per batch is left to the caller.
+ * species_pos / dtype / location / frame_stride / frames as in mdx_rdf_accumulate.
+ */
+int mdx_adf_num_combinations(int n_species);
+int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location,
+                       int n_species, const int64_t *n_per_species, int64_t frame_stride,
+                       const int64_t *frames, int64_t n_frames, const float box[3],
+                       float cutoff, int nbins, const double *bin_edges, float norm_power,
+                       double *hist, uint64_t *triple_counts);
+
 /* ------------------------------------------- coordinate transformations */
 /*
  * Per-atom transformations of [n_atoms][n_frames][3] arrays into arrays of the same

@@ -88,6 +88,13 @@ SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_int]),
+    "mdx_adf_num_combinations": (ctypes.c_int, [ctypes.c_int]),
+    "mdx_adf_accumulate": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, c_i64_p, ctypes.c_int64,
+                                          c_i64_p, ctypes.c_int64,
+                                          ctypes.POINTER(ctypes.c_float), ctypes.c_float,
+                                          ctypes.c_int, c_f64_p, ctypes.c_float, c_f64_p,
+                                          ctypes.POINTER(ctypes.c_uint64)]),
     "mdx_unwrap_coordinates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int64, ctypes.c_int64, c_f64_p,
                                               ctypes.c_int, c_f64_p, c_f64_p, ctypes.c_void_p,

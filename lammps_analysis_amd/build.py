@@ -21,7 +21,7 @@ LIB_PATH = LIB_DIR / "libmdx.so"
 OBJ_DIR = PACKAGE_DIR / "build"
 
 SOURCES = ["mdx_runtime.hip", "mdx_rdf.hip", "mdx_reduce.hip", "mdx_corr.hip",
-           "mdx_transform.hip"]
+           "mdx_transform.hip", "mdx_adf.hip"]
 
 HIPCC_FLAGS = [
     "-O3",

@@ -1,4 +1,5 @@
 """Calculators of the accelerated path (same names as mdsuite.calculators)."""
+from .angular_distribution_function import AngularDistributionFunction
 from .einstein_diffusion_coefficients import EinsteinDiffusionCoefficients
 from .einstein_distinct_diffusion_coefficients import EinsteinDistinctDiffusionCoefficients
 from .einstein_helfand_ionic_conductivity import EinsteinHelfandIonicConductivity
@@ -11,7 +12,7 @@ from .green_kubo_viscosity import GreenKuboViscosity
 from .green_kubo_viscosity_flux import GreenKuboViscosityFlux
 from .radial_distribution_function import RadialDistributionFunction
 
-__all__ = ["EinsteinDiffusionCoefficients", "EinsteinDistinctDiffusionCoefficients",
+__all__ = ["AngularDistributionFunction", "EinsteinDiffusionCoefficients", "EinsteinDistinctDiffusionCoefficients",
            "GreenKuboDistinctDiffusionCoefficients", "EinsteinHelfandIonicConductivity",
            "GreenKuboIonicConductivity", "GreenKuboDiffusionCoefficients",
            "GreenKuboThermalConductivity", "GreenKuboViscosity", "GreenKuboViscosityFlux",

@@ -1,0 +1,348 @@
+// Angular distribution function: weighted histograms of the angle at atom i between
+// all ordered pairs of its neighbours (j, k), j != k, both inside the cutoff.
+//
+// Three passes per block of frames:
+//   adf_gather_kernel     species arrays [atoms][frames][3] -> X[frame][component][atom]
+//   adf_neighbour_kernel  thread = atom i, loop over every j: literal float32 minimum
+//                         image, distance, cutoff test in float16 as the reference
+//                         does; first run counts the neighbours, second run stores
+//                         them (index, unit vector, length) in per-atom lists
+//   adf_triplet_kernel    wave = atom i, lanes stride over the ordered neighbour pairs:
+//                         angle = acos(clamp(u_ij . u_ik)), weight = 1 / (|r_ij| |r_ik|)^p,
+//                         float64 LDS histograms per species triple, flushed once
+//
+// The pair search is the same N^2 loop as the radial distribution function; with
+// cutoffs of a few Angstrom a frame has ~N * n^2 triplets (n ~ 30 neighbours), far
+// less work.  Compiled with -ffp-contract=off and correctly rounded divide / sqrt,
+// so the vectors, lengths and unit vectors are bit-identical to a float32 NumPy
+// evaluation; acosf / powf may differ from other libraries in the last place.
+#include "mdx_common.h"
+
+using namespace mdx;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxAdfSpecies = 8;
+
+struct AdfBox {
+  float box[3];
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void adf_gather_kernel(
+    const void *const *__restrict__ species_ptr, const int32_t *__restrict__ atom_species,
+    const int32_t *__restrict__ atom_local, const int64_t *__restrict__ frames, int64_t f0,
+    int64_t frame_stride, int nf, int64_t n_atoms, float *__restrict__ X) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= n_atoms * nf) return;
+  const int64_t a = e % n_atoms;
+  const int64_t fl = e / n_atoms;
+  const int64_t frame = frames ? frames[fl] : f0 + fl;
+  const T *src = static_cast<const T *>(species_ptr[atom_species[a]]) +
+                 (static_cast<int64_t>(atom_local[a]) * frame_stride + frame) * 3;
+  float *dst = X + fl * 3 * n_atoms + a;
+  dst[0] = static_cast<float>(src[0]);
+  dst[n_atoms] = static_cast<float>(src[1]);
+  dst[2 * n_atoms] = static_cast<float>(src[2]);
+}
+
+// kStore == false: counts[frame][i] = number of neighbours.
+// kStore == true : fills nbr_index / nbr_vec [frame][i][capacity] (vec = unit vector,
+//                  length) in increasing j.
+template <bool kStore>
+__global__ __launch_bounds__(kThreads) void adf_neighbour_kernel(
+    const float *__restrict__ X, int64_t n_atoms, AdfBox p, float cutoff, int capacity,
+    int32_t *__restrict__ counts, int32_t *__restrict__ nbr_index,
+    float4 *__restrict__ nbr_vec) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t f = blockIdx.y;
+  const float *x = X + f * 3 * n_atoms;
+  const float *y = x + n_atoms;
+  const float *z = y + n_atoms;
+  const bool active = i < n_atoms;
+  const float xi = active ? x[i] : 0.0f;
+  const float yi = active ? y[i] : 0.0f;
+  const float zi = active ? z[i] : 0.0f;
+  const _Float16 cut16 = static_cast<_Float16>(cutoff);
+  int n = 0;
+  const int64_t base = (f * n_atoms + i) * capacity;
+  for (int64_t j = 0; j < n_atoms; ++j) {
+    float rx = xi - x[j];
+    float ry = yi - y[j];
+    float rz = zi - z[j];
+    rx = rx - rintf(rx / p.box[0]) * p.box[0];
+    ry = ry - rintf(ry / p.box[1]) * p.box[1];
+    rz = rz - rintf(rz / p.box[2]) * p.box[2];
+    const float d = sqrtf((rx * rx + ry * ry) + rz * rz);
+    _Float16 d16 = static_cast<_Float16>(d);
+    // a zero distance (the atom itself) counts as the cutoff, i.e. outside
+    const bool inside = active && (d16 != static_cast<_Float16>(0.0f)) && (d16 < cut16);
+    if (inside) {
+      if (kStore && n < capacity) {
+        nbr_index[base + n] = static_cast<int32_t>(j);
+        nbr_vec[base + n] = make_float4(rx / d, ry / d, rz / d, d);
+      }
+      ++n;
+    }
+  }
+  if (!kStore && active) counts[f * n_atoms + i] = n;
+}
+
+// hist[combo][bin] (float64) and triples[combo] accumulate over the launch.
+// LDS: double hist[n_combos * nbins] | double edges[nbins + 1] | uint32 count[n_combos]
+__global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
+    const int32_t *__restrict__ counts, const int32_t *__restrict__ nbr_index,
+    const float4 *__restrict__ nbr_vec, const int32_t *__restrict__ atom_species,
+    const int32_t *__restrict__ combo_of, int n_species, int n_combos, int64_t n_atoms,
+    int capacity, int atoms_per_block, int nbins, const double *__restrict__ g_edges,
+    float norm_power, double *__restrict__ g_hist, unsigned long long *__restrict__ g_triples) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *hist = reinterpret_cast<double *>(lds_raw);
+  double *edges = hist + static_cast<size_t>(n_combos) * nbins;
+  uint32_t *count = reinterpret_cast<uint32_t *>(edges + nbins + 1);
+  for (int b = threadIdx.x; b < n_combos * nbins; b += kThreads) hist[b] = 0.0;
+  for (int b = threadIdx.x; b <= nbins; b += kThreads) edges[b] = g_edges[b];
+  for (int b = threadIdx.x; b < n_combos; b += kThreads) count[b] = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t f = blockIdx.y;
+  const int64_t i_begin = static_cast<int64_t>(blockIdx.x) * atoms_per_block;
+  const int64_t i_end = min(n_atoms, i_begin + atoms_per_block);
+  const double first = edges[0];
+  const double scale = static_cast<double>(nbins) / (edges[nbins] - edges[0]);
+  for (int64_t i = i_begin + wave; i < i_end; i += kThreads / 64) {
+    const int n = min(counts[f * n_atoms + i], capacity);
+    const int64_t base = (f * n_atoms + i) * capacity;
+    const int si = atom_species[i];
+    const int n_pairs = n * n;
+    for (int pidx = lane; pidx < n_pairs; pidx += 64) {
+      const int a = pidx / n;
+      const int b = pidx - a * n;
+      if (a == b) continue;
+      const int j = nbr_index[base + a];
+      const int k = nbr_index[base + b];
+      const int combo = combo_of[(si * n_species + atom_species[j]) * n_species +
+                                 atom_species[k]];
+      if (combo < 0) continue;
+      const float4 va = nbr_vec[base + a];
+      const float4 vb = nbr_vec[base + b];
+      float dot = (va.x * vb.x + va.y * vb.y) + va.z * vb.z;
+      dot = fminf(fmaxf(dot, -1.0f), 1.0f);
+      const float angle = acosf(dot);
+      const float weight = 1.0f / powf(va.w * vb.w, norm_power);
+      const double v = static_cast<double>(angle);
+      if (!(v >= first) || !(v <= edges[nbins])) continue;  // outside the range (or NaN)
+      int bin = static_cast<int>((v - first) * scale);
+      bin = max(0, min(bin, nbins - 1));
+      while (bin > 0 && v < edges[bin]) --bin;
+      while (bin < nbins - 1 && v >= edges[bin + 1]) ++bin;
+      atomicAdd(&hist[combo * nbins + bin], static_cast<double>(weight));
+      atomicAdd(&count[combo], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_combos * nbins; b += kThreads) {
+    const double v = hist[b];
+    if (v != 0.0) atomicAdd(&g_hist[b], v);
+  }
+  for (int b = threadIdx.x; b < n_combos; b += kThreads)
+    if (count[b] != 0u) atomicAdd(&g_triples[b], static_cast<unsigned long long>(count[b]));
+}
+
+__global__ void adf_max_kernel(const int32_t *__restrict__ counts, int64_t n,
+                               int32_t *__restrict__ out) {
+  int m = 0;
+  for (int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; e < n;
+       e += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    m = max(m, counts[e]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdx_adf_num_combinations(int n_species) {
+  return n_species * (n_species + 1) * (n_species + 2) / 6;
+}
+
+int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, int n_species,
+                       const int64_t *n_per_species, int64_t frame_stride,
+                       const int64_t *frames, int64_t n_frames, const float box[3],
+                       float cutoff, int nbins, const double *bin_edges, float norm_power,
+                       double *hist, uint64_t *triple_counts) {
+  MDX_REQUIRE(species_pos != nullptr && n_per_species != nullptr && box != nullptr &&
+                  bin_edges != nullptr && hist != nullptr && triple_counts != nullptr,
+              "null argument");
+  MDX_REQUIRE(dtype == MDX_F32 || dtype == MDX_F64, "dtype must be MDX_F32 or MDX_F64");
+  MDX_REQUIRE(location == MDX_HOST || location == MDX_DEVICE, "bad location");
+  MDX_REQUIRE(n_species >= 1 && n_species <= kMaxAdfSpecies, "n_species out of range (1..%d)",
+              kMaxAdfSpecies);
+  MDX_REQUIRE(nbins >= 1 && cutoff > 0.0f, "nbins and cutoff must be positive");
+  MDX_REQUIRE(n_frames >= 0 && frame_stride >= 0, "negative frame count");
+  for (int c = 0; c < 3; ++c) MDX_REQUIRE(box[c] > 0.0f, "box lengths must be positive");
+  for (int b = 0; b < nbins; ++b)
+    MDX_REQUIRE(bin_edges[b] < bin_edges[b + 1], "bin edges must increase");
+  int64_t n_atoms = 0;
+  for (int s = 0; s < n_species; ++s) {
+    MDX_REQUIRE(n_per_species[s] >= 0, "negative species size");
+    n_atoms += n_per_species[s];
+  }
+  MDX_REQUIRE(n_atoms < (int64_t(1) << 31), "too many atoms");
+  if (frames != nullptr) {
+    for (int64_t i = 0; i < n_frames; ++i)
+      MDX_REQUIRE(frames[i] >= 0 && frames[i] < frame_stride, "frame index out of range");
+  } else {
+    MDX_REQUIRE(n_frames <= frame_stride, "n_frames exceeds frame_stride");
+  }
+  if (n_frames == 0 || n_atoms == 0) return MDX_OK;
+
+  const int n_combos = mdx_adf_num_combinations(n_species);
+  const size_t lds = sizeof(double) * (static_cast<size_t>(n_combos) * nbins + nbins + 1) +
+                     sizeof(uint32_t) * n_combos + 16;
+  MDX_REQUIRE(lds <= 160 * 1024 - 512,
+              "%d species triples x %d bins need %zu bytes of LDS per workgroup", n_combos,
+              nbins, lds);
+
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  // atom tables and the species-triple lookup (combinations with replacement, in order)
+  std::vector<int32_t> atom_species(n_atoms), atom_local(n_atoms);
+  {
+    int64_t a = 0;
+    for (int s = 0; s < n_species; ++s)
+      for (int64_t l = 0; l < n_per_species[s]; ++l, ++a) {
+        atom_species[a] = s;
+        atom_local[a] = static_cast<int32_t>(l);
+      }
+  }
+  std::vector<int32_t> combo_of(static_cast<size_t>(n_species) * n_species * n_species, -1);
+  {
+    int id = 0;
+    for (int a = 0; a < n_species; ++a)
+      for (int b = a; b < n_species; ++b)
+        for (int c = b; c < n_species; ++c)
+          combo_of[(static_cast<size_t>(a) * n_species + b) * n_species + c] = id++;
+  }
+  const size_t elem = dtype_size(dtype);
+  std::vector<DeviceBuffer> staged(location == MDX_HOST ? n_species : 0);
+  std::vector<const void *> ptrs(n_species, nullptr);
+  for (int s = 0; s < n_species; ++s) {
+    if (n_per_species[s] == 0) continue;
+    MDX_REQUIRE(species_pos[s] != nullptr, "positions of species %d are null", s);
+    if (location == MDX_HOST) {
+      MDX_TRY(to_device(species_pos[s], MDX_HOST,
+                        static_cast<size_t>(n_per_species[s]) * frame_stride * 3 * elem,
+                        staged[s], stream, &ptrs[s]));
+    } else {
+      ptrs[s] = species_pos[s];
+    }
+  }
+  DeviceBuffer d_ptrs, d_species, d_local, d_combo, d_frames, d_edges, d_hist, d_triples;
+  MDX_TRY(d_ptrs.alloc(sizeof(void *) * n_species));
+  MDX_TRY(d_species.alloc(sizeof(int32_t) * n_atoms));
+  MDX_TRY(d_local.alloc(sizeof(int32_t) * n_atoms));
+  MDX_TRY(d_combo.alloc(sizeof(int32_t) * combo_of.size()));
+  MDX_TRY(d_edges.alloc(sizeof(double) * (nbins + 1)));
+  MDX_TRY(d_hist.alloc(sizeof(double) * n_combos * nbins));
+  MDX_TRY(d_triples.alloc(sizeof(unsigned long long) * n_combos));
+  MDX_HIP(hipMemcpyAsync(d_ptrs.ptr, ptrs.data(), sizeof(void *) * n_species,
+                         hipMemcpyHostToDevice, stream));
+  MDX_HIP(hipMemcpyAsync(d_species.ptr, atom_species.data(), sizeof(int32_t) * n_atoms,
+                         hipMemcpyHostToDevice, stream));
+  MDX_HIP(hipMemcpyAsync(d_local.ptr, atom_local.data(), sizeof(int32_t) * n_atoms,
+                         hipMemcpyHostToDevice, stream));
+  MDX_HIP(hipMemcpyAsync(d_combo.ptr, combo_of.data(), sizeof(int32_t) * combo_of.size(),
+                         hipMemcpyHostToDevice, stream));
+  MDX_HIP(hipMemcpyAsync(d_edges.ptr, bin_edges, sizeof(double) * (nbins + 1),
+                         hipMemcpyHostToDevice, stream));
+  MDX_HIP(hipMemsetAsync(d_hist.ptr, 0, sizeof(double) * n_combos * nbins, stream));
+  MDX_HIP(hipMemsetAsync(d_triples.ptr, 0, sizeof(unsigned long long) * n_combos, stream));
+  if (frames != nullptr) {
+    MDX_TRY(d_frames.alloc(sizeof(int64_t) * n_frames));
+    MDX_HIP(hipMemcpyAsync(d_frames.ptr, frames, sizeof(int64_t) * n_frames,
+                           hipMemcpyHostToDevice, stream));
+  }
+  MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(adf_triplet_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds)));
+
+  // frames per block of work: packed image and counts bounded to ~256 MiB
+  int64_t chunk = (int64_t(256) << 20) / (static_cast<int64_t>(n_atoms) * 16);
+  if (chunk < 1) chunk = 1;
+  if (chunk > n_frames) chunk = n_frames;
+  if (chunk > 65535) chunk = 65535;
+  DeviceBuffer d_X, d_counts, d_max, d_index, d_vec;
+  MDX_TRY(d_X.alloc(sizeof(float) * 3 * n_atoms * chunk));
+  MDX_TRY(d_counts.alloc(sizeof(int32_t) * n_atoms * chunk));
+  MDX_TRY(d_max.alloc(sizeof(int32_t)));
+  AdfBox p{{box[0], box[1], box[2]}};
+  const unsigned atom_blocks = static_cast<unsigned>(ceil_div(n_atoms, kThreads));
+  for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
+    const int nf = static_cast<int>(std::min<int64_t>(chunk, n_frames - f0));
+    const dim3 ggrid(static_cast<unsigned>(ceil_div(n_atoms * nf, kThreads)));
+    const int64_t *fl = frames ? d_frames.as<int64_t>() + f0 : nullptr;
+    if (dtype == MDX_F32) {
+      hipLaunchKernelGGL(adf_gather_kernel<float>, ggrid, dim3(kThreads), 0, stream,
+                         d_ptrs.as<const void *>(), d_species.as<int32_t>(),
+                         d_local.as<int32_t>(), fl, f0, frame_stride, nf, n_atoms,
+                         d_X.as<float>());
+    } else {
+      hipLaunchKernelGGL(adf_gather_kernel<double>, ggrid, dim3(kThreads), 0, stream,
+                         d_ptrs.as<const void *>(), d_species.as<int32_t>(),
+                         d_local.as<int32_t>(), fl, f0, frame_stride, nf, n_atoms,
+                         d_X.as<float>());
+    }
+    MDX_HIP(hipGetLastError());
+    const dim3 ngrid(atom_blocks, static_cast<unsigned>(nf));
+    hipLaunchKernelGGL(adf_neighbour_kernel<false>, ngrid, dim3(kThreads), 0, stream,
+                       d_X.as<float>(), n_atoms, p, cutoff, 0, d_counts.as<int32_t>(),
+                       static_cast<int32_t *>(nullptr), static_cast<float4 *>(nullptr));
+    MDX_HIP(hipGetLastError());
+    MDX_HIP(hipMemsetAsync(d_max.ptr, 0, sizeof(int32_t), stream));
+    hipLaunchKernelGGL(adf_max_kernel, dim3(256), dim3(kThreads), 0, stream,
+                       d_counts.as<int32_t>(), n_atoms * nf, d_max.as<int32_t>());
+    MDX_HIP(hipGetLastError());
+    int32_t capacity = 0;
+    MDX_HIP(hipMemcpyAsync(&capacity, d_max.ptr, sizeof(int32_t), hipMemcpyDeviceToHost,
+                           stream));
+    MDX_HIP(hipStreamSynchronize(stream));
+    if (capacity < 2) continue;  // no atom has two neighbours: no triplets
+    const size_t slots = static_cast<size_t>(n_atoms) * nf * capacity;
+    MDX_REQUIRE(slots * 20 <= (size_t(64) << 30),
+                "neighbour lists need %zu bytes (largest neighbourhood %d atoms)", slots * 20,
+                capacity);
+    MDX_TRY(d_index.reserve(sizeof(int32_t) * slots));
+    MDX_TRY(d_vec.reserve(sizeof(float4) * slots));
+    hipLaunchKernelGGL(adf_neighbour_kernel<true>, ngrid, dim3(kThreads), 0, stream,
+                       d_X.as<float>(), n_atoms, p, cutoff, capacity, d_counts.as<int32_t>(),
+                       d_index.as<int32_t>(), d_vec.as<float4>());
+    MDX_HIP(hipGetLastError());
+    const int atoms_per_block = 64;
+    const dim3 tgrid(static_cast<unsigned>(ceil_div(n_atoms, atoms_per_block)),
+                     static_cast<unsigned>(nf));
+    hipLaunchKernelGGL(adf_triplet_kernel, tgrid, dim3(kThreads), lds, stream,
+                       d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>(),
+                       d_species.as<int32_t>(), d_combo.as<int32_t>(), n_species, n_combos,
+                       n_atoms, capacity, atoms_per_block, nbins, d_edges.as<double>(),
+                       norm_power, d_hist.as<double>(),
+                       d_triples.as<unsigned long long>());
+    MDX_HIP(hipGetLastError());
+  }
+  std::vector<double> h_hist(static_cast<size_t>(n_combos) * nbins);
+  std::vector<unsigned long long> h_triples(n_combos);
+  MDX_HIP(hipMemcpyAsync(h_hist.data(), d_hist.ptr, sizeof(double) * h_hist.size(),
+                         hipMemcpyDeviceToHost, stream));
+  MDX_HIP(hipMemcpyAsync(h_triples.data(), d_triples.ptr,
+                         sizeof(unsigned long long) * n_combos, hipMemcpyDeviceToHost,
+                         stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  for (size_t b = 0; b < h_hist.size(); ++b) hist[b] += h_hist[b];
+  for (int c = 0; c < n_combos; ++c) triple_counts[c] += h_triples[c];
+  return MDX_OK;
+}
+
+}  // extern "C"

@@ -301,6 +301,53 @@ def thermal_flux(stress: ArrayLike, vel: ArrayLike, ke: ArrayLike, pe: ArrayLike
     return out
 
 
+# ------------------------------------------------ angular distribution function
+
+def adf_accumulate(species_positions: Sequence[ArrayLike], box, cutoff: float,
+                   bin_edges: np.ndarray, norm_power: float = 4.0, frames=None):
+    """Weighted angle histograms of one batch of frames; see ``mdx_adf_accumulate``.
+
+    ``species_positions[s]`` is ``[n_s, F, 3]``.  Returns ``(hist, triples)``: float64
+    ``[n_combinations, nbins]`` weight sums and uint64 ``[n_combinations]`` triple counts,
+    combinations with replacement of the species in their given order.
+    """
+    infos = [_as_input(p) for p in species_positions]
+    if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
+        raise ValueError("all species arrays must share location and dtype")
+    n_species = len(infos)
+    strides = set()
+    for info in infos:
+        if len(info[3]) != 3 or info[3][2] != 3:
+            raise ValueError(f"expected shape (n, F, 3), got {info[3]}")
+        strides.add(info[3][1])
+    if len(strides) != 1:
+        raise ValueError("all species arrays must hold the same number of frames")
+    frame_stride = strides.pop()
+    n_per_species = np.ascontiguousarray([i[3][0] for i in infos], dtype=np.int64)
+    ptrs = (ctypes.c_void_p * n_species)(*[i[0] for i in infos])
+    if frames is None:
+        frames_ptr, n_frames = None, frame_stride
+    else:
+        frames_arr = np.ascontiguousarray(frames, dtype=np.int64)
+        frames_ptr, n_frames = frames_arr.ctypes.data_as(_lib.c_i64_p), len(frames_arr)
+    edges = np.ascontiguousarray(bin_edges, dtype=np.float64)
+    nbins = len(edges) - 1
+    lib = _lib.load()
+    n_combos = lib.mdx_adf_num_combinations(n_species)
+    hist = np.zeros((n_combos, nbins), dtype=np.float64)
+    triples = np.zeros(n_combos, dtype=np.uint64)
+    box_arr = np.ascontiguousarray(np.asarray(box, dtype=np.float32).reshape(-1))
+    if box_arr.size != 3:
+        raise ValueError("box must have three entries")
+    check(lib.mdx_adf_accumulate(
+        ptrs, infos[0][1], infos[0][2], n_species, n_per_species.ctypes.data_as(_lib.c_i64_p),
+        frame_stride, frames_ptr, n_frames,
+        box_arr.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), float(np.float32(cutoff)),
+        nbins, edges.ctypes.data_as(_lib.c_f64_p), float(norm_power),
+        hist.ctypes.data_as(_lib.c_f64_p), triples.ctypes.data_as(_lib.c_u64_p)))
+    return hist, triples
+
+
 # ------------------------------------------------- coordinate transformations
 
 MAP_WRAP, MAP_WRAP_CENTERED, MAP_SCALE, MAP_UNWRAP_INDICES, MAP_VELOCITY = range(5)

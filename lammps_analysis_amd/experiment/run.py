@@ -90,6 +90,10 @@ class RunComputation:
         return self.exp_wrapper(getattr(calculators, name))(**self.kwargs)
 
     @property
+    def AngularDistributionFunction(self):
+        return self._calculator("AngularDistributionFunction")
+
+    @property
     def RadialDistributionFunction(self):
         return self._calculator("RadialDistributionFunction")
 
