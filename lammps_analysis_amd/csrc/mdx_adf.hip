@@ -6,7 +6,8 @@
 //   adf_neighbour_kernel  thread = atom i, loop over every j: literal float32 minimum
 //                         image, distance, cutoff test in float16 as the reference
 //                         does; first run counts the neighbours, second run stores
-//                         them (index, unit vector, length) in per-atom lists
+//                         them (index, unit vector, length) in per-atom lists;
+//                         grid.z splits the j loop so that few frames fill the chip
 //   adf_triplet_kernel    wave = atom i, lanes stride over the ordered neighbour pairs:
 //                         angle = acos(clamp(u_ij . u_ik)), weight = 1 / (|r_ij| |r_ik|)^p,
 //                         float64 LDS histograms per species triple, flushed once
@@ -24,6 +25,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxAdfSpecies = 8;
+constexpr int kCountCopies = 32;
 
 struct AdfBox {
   float box[3];
@@ -33,64 +35,120 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void adf_gather_kernel(
     const void *const *__restrict__ species_ptr, const int32_t *__restrict__ atom_species,
     const int32_t *__restrict__ atom_local, const int64_t *__restrict__ frames, int64_t f0,
-    int64_t frame_stride, int nf, int64_t n_atoms, float *__restrict__ X) {
+    int64_t frame_stride, int nf, int64_t n_atoms, int64_t n_pad, float *__restrict__ X) {
+  // n_pad = n_atoms rounded up to a multiple of 4; the padding slots hold NaN, which
+  // is never inside a cutoff
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (e >= n_atoms * nf) return;
-  const int64_t a = e % n_atoms;
-  const int64_t fl = e / n_atoms;
+  if (e >= n_pad * nf) return;
+  const int64_t a = e % n_pad;
+  const int64_t fl = e / n_pad;
+  float *dst = X + fl * 3 * n_pad + a;
+  if (a >= n_atoms) {
+    const float nan = __builtin_nanf("");
+    dst[0] = nan;
+    dst[n_pad] = nan;
+    dst[2 * n_pad] = nan;
+    return;
+  }
   const int64_t frame = frames ? frames[fl] : f0 + fl;
   const T *src = static_cast<const T *>(species_ptr[atom_species[a]]) +
                  (static_cast<int64_t>(atom_local[a]) * frame_stride + frame) * 3;
-  float *dst = X + fl * 3 * n_atoms + a;
   dst[0] = static_cast<float>(src[0]);
-  dst[n_atoms] = static_cast<float>(src[1]);
-  dst[2 * n_atoms] = static_cast<float>(src[2]);
+  dst[n_pad] = static_cast<float>(src[1]);
+  dst[2 * n_pad] = static_cast<float>(src[2]);
 }
 
-// kStore == false: counts[frame][i] = number of neighbours.
-// kStore == true : fills nbr_index / nbr_vec [frame][i][capacity] (vec = unit vector,
-//                  length) in increasing j.
+// A block covers 256 atoms i and a chunk of atoms j (grid.z); counts[frame][i] must be
+// zero at launch.
+// kStore == false: counts[frame][i] += neighbours found in the chunk.
+// kStore == true : the same, and every neighbour takes the next free slot of
+//                  nbr_index / nbr_vec [frame][i][capacity] (vec = unit vector, length);
+//                  the order of a list therefore varies from run to run.
 template <bool kStore>
 __global__ __launch_bounds__(kThreads) void adf_neighbour_kernel(
-    const float *__restrict__ X, int64_t n_atoms, AdfBox p, float cutoff, int capacity,
-    int32_t *__restrict__ counts, int32_t *__restrict__ nbr_index,
-    float4 *__restrict__ nbr_vec) {
+    const float *__restrict__ X, int64_t n_atoms, int64_t n_pad, AdfBox p, float cutoff,
+    int capacity, int64_t j_chunk, int32_t *__restrict__ counts,
+    int32_t *__restrict__ nbr_index, float4 *__restrict__ nbr_vec) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   const int64_t f = blockIdx.y;
-  const float *x = X + f * 3 * n_atoms;
-  const float *y = x + n_atoms;
-  const float *z = y + n_atoms;
+  const float *x = X + f * 3 * n_pad;
+  const float *y = x + n_pad;
+  const float *z = y + n_pad;
   const bool active = i < n_atoms;
   const float xi = active ? x[i] : 0.0f;
   const float yi = active ? y[i] : 0.0f;
   const float zi = active ? z[i] : 0.0f;
   const _Float16 cut16 = static_cast<_Float16>(cutoff);
+  const float inv_box[3] = {1.0f / p.box[0], 1.0f / p.box[1], 1.0f / p.box[2]};
+  const float s_far = (cutoff * 1.002f) * (cutoff * 1.002f);
   int n = 0;
   const int64_t base = (f * n_atoms + i) * capacity;
-  for (int64_t j = 0; j < n_atoms; ++j) {
-    float rx = xi - x[j];
-    float ry = yi - y[j];
-    float rz = zi - z[j];
-    rx = rx - rintf(rx / p.box[0]) * p.box[0];
-    ry = ry - rintf(ry / p.box[1]) * p.box[1];
-    rz = rz - rintf(rz / p.box[2]) * p.box[2];
-    const float d = sqrtf((rx * rx + ry * ry) + rz * rz);
-    _Float16 d16 = static_cast<_Float16>(d);
-    // a zero distance (the atom itself) counts as the cutoff, i.e. outside
-    const bool inside = active && (d16 != static_cast<_Float16>(0.0f)) && (d16 < cut16);
-    if (inside) {
-      if (kStore && n < capacity) {
-        nbr_index[base + n] = static_cast<int32_t>(j);
-        nbr_vec[base + n] = make_float4(rx / d, ry / d, rz / d, d);
+  // j_chunk is a multiple of 4: four j atoms per wave-uniform 16-byte load
+  const int64_t j_begin = static_cast<int64_t>(blockIdx.z) * j_chunk;
+  const int64_t j_end = min(n_pad, j_begin + j_chunk);
+  for (int64_t j0 = j_begin; j0 < j_end; j0 += 4) {
+    const float4 xs = *reinterpret_cast<const float4 *>(x + j0);
+    const float4 ys = *reinterpret_cast<const float4 *>(y + j0);
+    const float4 zs = *reinterpret_cast<const float4 *>(z + j0);
+    const float xj[4] = {xs.x, xs.y, xs.z, xs.w};
+    const float yj[4] = {ys.x, ys.y, ys.z, ys.w};
+    const float zj[4] = {zs.x, zs.y, zs.z, zs.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float rx = xi - xj[u];
+      float ry = yi - yj[u];
+      float rz = zi - zj[u];
+      // literal rint(r / box), without the divide unless the quotient is close to a tie
+      rx = rx - exact_rint_quotient(rx, p.box[0], inv_box[0]) * p.box[0];
+      ry = ry - exact_rint_quotient(ry, p.box[1], inv_box[1]) * p.box[1];
+      rz = rz - exact_rint_quotient(rz, p.box[2], inv_box[2]) * p.box[2];
+      const float s = (rx * rx + ry * ry) + rz * rz;
+      // far pairs leave here, usually the whole wave at once: float16 rounding can
+      // admit distances up to cutoff * (1 + 2^-11) only; NaN (padding) fails the
+      // comparison too
+      const bool near = s < s_far;
+      if (__builtin_amdgcn_ballot_w64(near) == 0) continue;
+      if (!near) continue;
+      const float d = sqrtf(s);
+      const _Float16 d16 = static_cast<_Float16>(d);
+      // a zero distance (the atom itself) counts as the cutoff, i.e. outside; NaN
+      // (padding) fails the comparison
+      const bool inside = active && (d16 != static_cast<_Float16>(0.0f)) && (d16 < cut16);
+      if (inside) {
+        if (kStore) {
+          const int slot = atomicAdd(&counts[f * n_atoms + i], 1);
+          if (slot < capacity) {
+            nbr_index[base + slot] = static_cast<int32_t>(j0 + u);
+            nbr_vec[base + slot] = make_float4(rx / d, ry / d, rz / d, d);
+          }
+        } else {
+          ++n;
+        }
       }
-      ++n;
     }
   }
-  if (!kStore && active) counts[f * n_atoms + i] = n;
+  if (!kStore && active && n > 0) atomicAdd(&counts[f * n_atoms + i], n);
+}
+
+// x^p: repeated multiplication for the integer powers 0..8 (within 2 ulp of powf, and
+// far cheaper), powf otherwise.
+__device__ __forceinline__ float small_power(float x, float p, int int_power) {
+  if (int_power < 0) return powf(x, p);
+  float r = 1.0f;
+  float b = x;
+  int e = int_power;
+  while (e > 0) {
+    if (e & 1) r = r * b;
+    b = b * b;
+    e >>= 1;
+  }
+  return r;
 }
 
 // hist[combo][bin] (float64) and triples[combo] accumulate over the launch.
-// LDS: double hist[n_combos * nbins] | double edges[nbins + 1] | uint32 count[n_combos]
+// LDS: double hist[n_combos * nbins] | double edges[nbins + 1] |
+//      uint32 count[n_combos][kCountCopies] (one copy per lane pair: the lanes of a wave
+//      mostly count the same species triple)
 __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
     const int32_t *__restrict__ counts, const int32_t *__restrict__ nbr_index,
     const float4 *__restrict__ nbr_vec, const int32_t *__restrict__ atom_species,
@@ -103,7 +161,7 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
   uint32_t *count = reinterpret_cast<uint32_t *>(edges + nbins + 1);
   for (int b = threadIdx.x; b < n_combos * nbins; b += kThreads) hist[b] = 0.0;
   for (int b = threadIdx.x; b <= nbins; b += kThreads) edges[b] = g_edges[b];
-  for (int b = threadIdx.x; b < n_combos; b += kThreads) count[b] = 0u;
+  for (int b = threadIdx.x; b < n_combos * kCountCopies; b += kThreads) count[b] = 0u;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -112,6 +170,10 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
   const int64_t i_end = min(n_atoms, i_begin + atoms_per_block);
   const double first = edges[0];
   const double scale = static_cast<double>(nbins) / (edges[nbins] - edges[0]);
+  const int int_power =
+      (norm_power >= 0.0f && norm_power <= 8.0f && norm_power == rintf(norm_power))
+          ? static_cast<int>(norm_power)
+          : -1;
   for (int64_t i = i_begin + wave; i < i_end; i += kThreads / 64) {
     const int n = min(counts[f * n_atoms + i], capacity);
     const int64_t base = (f * n_atoms + i) * capacity;
@@ -131,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
       float dot = (va.x * vb.x + va.y * vb.y) + va.z * vb.z;
       dot = fminf(fmaxf(dot, -1.0f), 1.0f);
       const float angle = acosf(dot);
-      const float weight = 1.0f / powf(va.w * vb.w, norm_power);
+      const float weight = 1.0f / small_power(va.w * vb.w, norm_power, int_power);
       const double v = static_cast<double>(angle);
       if (!(v >= first) || !(v <= edges[nbins])) continue;  // outside the range (or NaN)
       int bin = static_cast<int>((v - first) * scale);
@@ -139,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
       while (bin > 0 && v < edges[bin]) --bin;
       while (bin < nbins - 1 && v >= edges[bin + 1]) ++bin;
       atomicAdd(&hist[combo * nbins + bin], static_cast<double>(weight));
-      atomicAdd(&count[combo], 1u);
+      atomicAdd(&count[combo * kCountCopies + (lane & (kCountCopies - 1))], 1u);
     }
   }
   __syncthreads();
@@ -147,8 +209,11 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
     const double v = hist[b];
     if (v != 0.0) atomicAdd(&g_hist[b], v);
   }
-  for (int b = threadIdx.x; b < n_combos; b += kThreads)
-    if (count[b] != 0u) atomicAdd(&g_triples[b], static_cast<unsigned long long>(count[b]));
+  for (int b = threadIdx.x; b < n_combos; b += kThreads) {
+    unsigned long long total = 0;
+    for (int c = 0; c < kCountCopies; ++c) total += count[b * kCountCopies + c];
+    if (total != 0) atomicAdd(&g_triples[b], total);
+  }
 }
 
 __global__ void adf_max_kernel(const int32_t *__restrict__ counts, int64_t n,
@@ -202,7 +267,7 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
 
   const int n_combos = mdx_adf_num_combinations(n_species);
   const size_t lds = sizeof(double) * (static_cast<size_t>(n_combos) * nbins + nbins + 1) +
-                     sizeof(uint32_t) * n_combos + 16;
+                     sizeof(uint32_t) * n_combos * kCountCopies + 16;
   MDX_REQUIRE(lds <= 160 * 1024 - 512,
               "%d species triples x %d bins need %zu bytes of LDS per workgroup", n_combos,
               nbins, lds);
@@ -271,36 +336,46 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
                               static_cast<int>(lds)));
 
   // frames per block of work: packed image and counts bounded to ~256 MiB
-  int64_t chunk = (int64_t(256) << 20) / (static_cast<int64_t>(n_atoms) * 16);
+  const int64_t n_pad = (n_atoms + 3) / 4 * 4;
+  int64_t chunk = (int64_t(256) << 20) / (n_pad * 16);
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 65535) chunk = 65535;
   DeviceBuffer d_X, d_counts, d_max, d_index, d_vec;
-  MDX_TRY(d_X.alloc(sizeof(float) * 3 * n_atoms * chunk));
+  MDX_TRY(d_X.alloc(sizeof(float) * 3 * n_pad * chunk));
   MDX_TRY(d_counts.alloc(sizeof(int32_t) * n_atoms * chunk));
   MDX_TRY(d_max.alloc(sizeof(int32_t)));
   AdfBox p{{box[0], box[1], box[2]}};
   const unsigned atom_blocks = static_cast<unsigned>(ceil_div(n_atoms, kThreads));
   for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = static_cast<int>(std::min<int64_t>(chunk, n_frames - f0));
-    const dim3 ggrid(static_cast<unsigned>(ceil_div(n_atoms * nf, kThreads)));
+    const dim3 ggrid(static_cast<unsigned>(ceil_div(n_pad * nf, kThreads)));
     const int64_t *fl = frames ? d_frames.as<int64_t>() + f0 : nullptr;
     if (dtype == MDX_F32) {
       hipLaunchKernelGGL(adf_gather_kernel<float>, ggrid, dim3(kThreads), 0, stream,
                          d_ptrs.as<const void *>(), d_species.as<int32_t>(),
-                         d_local.as<int32_t>(), fl, f0, frame_stride, nf, n_atoms,
+                         d_local.as<int32_t>(), fl, f0, frame_stride, nf, n_atoms, n_pad,
                          d_X.as<float>());
     } else {
       hipLaunchKernelGGL(adf_gather_kernel<double>, ggrid, dim3(kThreads), 0, stream,
                          d_ptrs.as<const void *>(), d_species.as<int32_t>(),
-                         d_local.as<int32_t>(), fl, f0, frame_stride, nf, n_atoms,
+                         d_local.as<int32_t>(), fl, f0, frame_stride, nf, n_atoms, n_pad,
                          d_X.as<float>());
     }
     MDX_HIP(hipGetLastError());
-    const dim3 ngrid(atom_blocks, static_cast<unsigned>(nf));
+    // j chunks: enough blocks to fill the chip
+    int64_t j_chunks = ceil_div(2048, static_cast<int64_t>(atom_blocks) * nf);
+    if (j_chunks > ceil_div(n_atoms, 256)) j_chunks = ceil_div(n_atoms, 256);
+    if (j_chunks < 1) j_chunks = 1;
+    const int64_t j_chunk = (ceil_div(n_pad, j_chunks) + 3) / 4 * 4;
+    j_chunks = ceil_div(n_pad, j_chunk);
+    const dim3 ngrid(atom_blocks, static_cast<unsigned>(nf), static_cast<unsigned>(j_chunks));
+    const size_t count_bytes = sizeof(int32_t) * n_atoms * nf;
+    MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
     hipLaunchKernelGGL(adf_neighbour_kernel<false>, ngrid, dim3(kThreads), 0, stream,
-                       d_X.as<float>(), n_atoms, p, cutoff, 0, d_counts.as<int32_t>(),
-                       static_cast<int32_t *>(nullptr), static_cast<float4 *>(nullptr));
+                       d_X.as<float>(), n_atoms, n_pad, p, cutoff, 0, j_chunk,
+                       d_counts.as<int32_t>(), static_cast<int32_t *>(nullptr),
+                       static_cast<float4 *>(nullptr));
     MDX_HIP(hipGetLastError());
     MDX_HIP(hipMemsetAsync(d_max.ptr, 0, sizeof(int32_t), stream));
     hipLaunchKernelGGL(adf_max_kernel, dim3(256), dim3(kThreads), 0, stream,
@@ -317,9 +392,10 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
                 capacity);
     MDX_TRY(d_index.reserve(sizeof(int32_t) * slots));
     MDX_TRY(d_vec.reserve(sizeof(float4) * slots));
+    MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
     hipLaunchKernelGGL(adf_neighbour_kernel<true>, ngrid, dim3(kThreads), 0, stream,
-                       d_X.as<float>(), n_atoms, p, cutoff, capacity, d_counts.as<int32_t>(),
-                       d_index.as<int32_t>(), d_vec.as<float4>());
+                       d_X.as<float>(), n_atoms, n_pad, p, cutoff, capacity, j_chunk,
+                       d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>());
     MDX_HIP(hipGetLastError());
     const int atoms_per_block = 64;
     const dim3 tgrid(static_cast<unsigned>(ceil_div(n_atoms, atoms_per_block)),

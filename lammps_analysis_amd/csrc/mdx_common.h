@@ -122,4 +122,18 @@ inline size_t dtype_size(int dtype) { return dtype == MDX_F64 ? 8 : 4; }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// rint(r / box) in float32, exactly as the IEEE divide would give it: the product
+// with the rounded reciprocal is within a few ulp of the true quotient, so its
+// nearest integer is the right one unless the quotient lies that close to a
+// half-integer; only then the divide is executed.
+__device__ __forceinline__ float exact_rint_quotient(float r, float box, float inv_box) {
+  const float q = r * inv_box;
+  float n = rintf(q);
+  const float dist = fabsf(fabsf(q - n) - 0.5f);
+  if (__builtin_expect(dist <= fabsf(q) * 0x1p-20f + 0x1p-30f, 0)) {
+    n = rintf(r / box);
+  }
+  return n;
+}
+
 }  // namespace mdx

@@ -139,20 +139,6 @@ __device__ __forceinline__ void pair_literal(float xi, float yi, float zi, float
   }
 }
 
-// rint(r / box) in float32, exactly as the IEEE divide would give it: the product
-// with the rounded reciprocal is within a few ulp of the true quotient, so its
-// nearest integer is the right one unless the quotient lies that close to a
-// half-integer; only then the divide is executed.
-__device__ __forceinline__ float exact_rint_quotient(float r, float box, float inv_box) {
-  const float q = r * inv_box;
-  float n = rintf(q);
-  const float dist = fabsf(fabsf(q - n) - 0.5f);
-  if (__builtin_expect(dist <= fabsf(q) * 0x1p-20f + 0x1p-30f, 0)) {
-    n = rintf(r / box);
-  }
-  return n;
-}
-
 // Flags the frames whose coordinate differences all stay below t_far, so that
 // the minimum-image shift is at most one box length ("wrapped" frames).
 // One block per frame; NaN padding is ignored by fminf/fmaxf.
