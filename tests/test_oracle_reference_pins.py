@@ -243,3 +243,31 @@ def test_element_wise_coordinate_transformations():
     assert np.all(wrapped >= 0) and np.all(wrapped < box_l)
     centred = ort.wrap_coordinates(pos * 5 - 2, box_l, center_box=True)
     assert np.all(np.abs(centred) <= box_l / 2)
+
+
+# ------------------------------------------------- angular distribution function
+
+def test_adf_oracle_on_a_right_triangle():
+    """No offline test of the reference pins the ADF; the restatement is at least held
+    to geometry: a right isosceles triangle has one 90 degree and two 45 degree angles,
+    each seen from both neighbour orders, weighted by 1 / (|r_ij| |r_ik|)^p."""
+    from oracle import adf as ora
+    pos = [np.array([[[1.0, 1.0, 1.0]], [[2.0, 1.0, 1.0]], [[1.0, 2.0, 1.0]]],
+                    dtype=np.float32)]                       # [3 atoms, 1 frame, 3]
+    nbins = 315                                              # 0.01 rad per bin
+    out = ora.adf_batch(pos, [20.0, 20.0, 20.0], 3.0, nbins, 2)
+    hist, count, weight = out[(0, 0, 0)]
+    assert count == 6
+    w90 = 1.0 / (1.0 * 1.0) ** 2
+    w45 = 1.0 / (1.0 * np.sqrt(2.0)) ** 2
+    np.testing.assert_allclose(weight, 2 * w90 + 4 * w45, rtol=1e-6)
+    filled = np.nonzero(hist)[0]
+    assert list(filled) == [int(np.pi / 4 / 0.01), int(np.pi / 2 / 0.01)]
+    np.testing.assert_allclose(hist[filled[1]] / hist[filled[0]], (2 * w90) / (4 * w45),
+                               rtol=1e-5)
+    # the float16 cutoff test: 2.9995 rounds to 3.0 in float16 and is therefore outside,
+    # 2.998 rounds to 2.998047 and stays inside
+    for x, triples in ((2.9995, 0), (2.998, 2)):
+        far = [np.array([[[0.0, 0.0, 0.0]], [[x, 0.0, 0.0]], [[0.0, 1.0, 0.0]]],
+                        dtype=np.float32)]
+        assert ora.adf_batch(far, [50.0] * 3, 3.0, 10, 0)[(0, 0, 0)][1] == triples
