@@ -128,3 +128,17 @@ def test_adf_calculator_through_the_experiment(gpu, tmp_path):
         np.testing.assert_allclose(got["adf"], hist, rtol=0, atol=2e-4 * hist.max())
         np.testing.assert_allclose(got["angle"], labels)
         assert got["max_peak"] == labels[int(np.argmax(got["adf"]))]
+
+
+@pytest.mark.parametrize("x,triples", [(2.9995, 0), (2.998, 2), (1.0, 6)])
+def test_adf_float16_cutoff_edge_and_triangle(gpu, x, triples):
+    """Distances that round to the cutoff in float16 are outside, as in the reference."""
+    pos = [np.array([[[0.0, 0.0, 0.0]], [[x, 0.0, 0.0]], [[0.0, 1.0, 0.0]]], dtype=np.float32)]
+    edges = _edges(315)
+    hist, count = gpu.adf_accumulate(pos, [50.0] * 3, 3.0, edges, norm_power=2)
+    assert int(count[0]) == triples
+    ref_hist, ref_count, ref_weight = ora.adf_batch(pos, [50.0] * 3, 3.0, 315, 2)[(0, 0, 0)]
+    assert ref_count == triples
+    if triples:
+        np.testing.assert_allclose(hist[0].sum(), ref_weight, rtol=1e-6)
+        assert list(np.nonzero(hist[0])[0]) == list(np.nonzero(ref_hist)[0])
