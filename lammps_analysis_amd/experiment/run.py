@@ -90,6 +90,18 @@ class RunComputation:
         return self.exp_wrapper(getattr(calculators, name))(**self.kwargs)
 
     @property
+    def CoordinationNumbers(self):
+        return self._calculator("CoordinationNumbers")
+
+    @property
+    def PotentialOfMeanForce(self):
+        return self._calculator("PotentialOfMeanForce")
+
+    @property
+    def KirkwoodBuffIntegral(self):
+        return self._calculator("KirkwoodBuffIntegral")
+
+    @property
     def AngularDistributionFunction(self):
         return self._calculator("AngularDistributionFunction")
 
