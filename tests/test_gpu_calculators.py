@@ -240,3 +240,21 @@ def test_einstein_helfand_and_flux_calculators_run(gpu, tmp_path):
     pref = (1 / (3 * 59 * 1400.0 * u.boltzmann * box**3)) * (u.pressure**2 * u.volume * u.time / u.energy)
     np.testing.assert_allclose(visc["viscosity"], pref * sigma[0], rtol=1e-6)
     np.testing.assert_allclose(visc["uncertainty"], pref * sigma[1], rtol=1e-6)
+
+
+def test_kirkwood_buff_runs_its_own_rdf(gpu, tmp_path):
+    """A calculator that post-processes the RDF computes it (on the GPU, default
+    arguments) when none is handed in, and finds it again for the next consumer."""
+    rng = np.random.default_rng(77)
+    n_step, box = 12, [20.0, 20.0, 20.0]
+    os.chdir(tmp_path)
+    project = mds.Project()
+    exp = project.add_experiment("gas", timestep=0.1, temperature=100.0, units="metal")
+    _add(exp, {"Ar": {mdsuite_properties.positions: rng.random((n_step, 400, 3)) * 20.0}},
+         n_step, box_l=box)
+    kb = exp.run.KirkwoodBuffIntegral(plot=False)["Ar_Ar"]
+    rdf = exp.run.RadialDistributionFunction(plot=False)["Ar_Ar"]
+    assert len(kb["r"]) == len(rdf["x"]) - 2
+    assert np.all(np.isfinite(kb["kb_integral"]))
+    # an ideal gas has g(r) ~ 1: the integral stays small against the sphere volume
+    assert abs(kb["kb_integral"][-1]) < 0.2 * 4 / 3 * np.pi * kb["r"][-1] ** 3
