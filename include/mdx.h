@@ -186,6 +186,15 @@ int mdx_thermal_flux(const void *stress, const void *vel, const void *ke,
                      int64_t n_frames, double *out, int out_location,
                      int accumulate);
 
+/*
+ * out[t][:] (+)= sum_a x[a][t][:] * (ke[a][t] + pe[a][t]): IntegratedHeatCurrent.
+ * transform_batch (mdsuite/transformations/integrated_heat_current.py:35-60), x the
+ * unwrapped positions.  ke, pe are [n_atoms][n_frames][1].
+ */
+int mdx_energy_weighted_sum(const void *x, const void *ke, const void *pe, int dtype,
+                            int location, int64_t n_atoms, int64_t n_frames, double *out,
+                            int out_location, int accumulate);
+
 /* ------------------------------------------- angular distribution function */
 /*
  * Weighted angle histograms of all atom triples, one batch of configurations of

@@ -88,6 +88,10 @@ SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_int]),
+    "mdx_energy_weighted_sum": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int]),
     "mdx_adf_num_combinations": (ctypes.c_int, [ctypes.c_int]),
     "mdx_adf_accumulate": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_i64_p, ctypes.c_int64,

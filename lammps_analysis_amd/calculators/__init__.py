@@ -4,6 +4,7 @@ from .coordination_number_calculation import CoordinationNumbers
 from .einstein_diffusion_coefficients import EinsteinDiffusionCoefficients
 from .einstein_distinct_diffusion_coefficients import EinsteinDistinctDiffusionCoefficients
 from .einstein_helfand_ionic_conductivity import EinsteinHelfandIonicConductivity
+from .einstein_helfand_thermal_conductivity import EinsteinHelfandThermalConductivity
 from .green_kubo_distinct_diffusion_coefficients import \
     GreenKuboDistinctDiffusionCoefficients
 from .green_kubo_ionic_conductivity import GreenKuboIonicConductivity
@@ -18,6 +19,7 @@ from .radial_distribution_function import RadialDistributionFunction
 __all__ = ["AngularDistributionFunction", "CoordinationNumbers", "KirkwoodBuffIntegral",
            "PotentialOfMeanForce", "EinsteinDiffusionCoefficients", "EinsteinDistinctDiffusionCoefficients",
            "GreenKuboDistinctDiffusionCoefficients", "EinsteinHelfandIonicConductivity",
+           "EinsteinHelfandThermalConductivity",
            "GreenKuboIonicConductivity", "GreenKuboDiffusionCoefficients",
            "GreenKuboThermalConductivity", "GreenKuboViscosity", "GreenKuboViscosityFlux",
            "RadialDistributionFunction"]

@@ -151,6 +151,29 @@ __global__ __launch_bounds__(kThreads) void thermal_flux_kernel(
   }
 }
 
+// partial[chunk][t*3+c] = sum_a x[a][t][c] * (ke[a][t] + pe[a][t]); the energies are
+// added first, then multiplied, as in the reference expression.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void energy_weighted_kernel(
+    const T *__restrict__ x, const T *__restrict__ ke, const T *__restrict__ pe,
+    int64_t n_atoms, int64_t n_frames, int64_t atoms_per_chunk,
+    double *__restrict__ partial) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (t >= n_frames) return;
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int64_t a = a0; a < a1; ++a) {
+    const int64_t at = a * n_frames + t;
+    const double e = static_cast<double>(ke[at]) + static_cast<double>(pe[at]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = acc[i] + static_cast<double>(x[at * 3 + i]) * e;
+  }
+  double *dst = partial + static_cast<int64_t>(blockIdx.y) * n_frames * 3;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dst[t * 3 + i] = acc[i];
+}
+
 // out[col] (+)= sum over chunks, in chunk order.  planes == 2 combines the two
 // partial sums of the thermal flux as (sum of plane 0) - (sum of plane 1).
 __global__ __launch_bounds__(kThreads) void combine_chunks_kernel(
@@ -359,6 +382,41 @@ int mdx_thermal_flux(const void *stress, const void *vel, const void *ke, const 
                        n_atoms, n_frames, plan.atoms_per_chunk, partial.as<double>());
   MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 2, n_cols, out, out_location,
+                 accumulate, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+int mdx_energy_weighted_sum(const void *x, const void *ke, const void *pe, int dtype,
+                            int location, int64_t n_atoms, int64_t n_frames, double *out,
+                            int out_location, int accumulate) {
+  MDX_TRY(check_common(x, dtype, location, n_atoms, n_frames, out, out_location));
+  MDX_REQUIRE(ke != nullptr && pe != nullptr, "null argument");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  const int64_t n_cols = n_frames * 3;
+  if (n_atoms == 0 || n_cols == 0) return zero_result(out, out_location, n_cols, accumulate, stream);
+  DeviceBuffer st_x, st_k, st_p, partial;
+  const void *dx = nullptr, *dk = nullptr, *dp = nullptr;
+  const size_t unit = static_cast<size_t>(n_atoms) * n_frames * dtype_size(dtype);
+  MDX_TRY(to_device(x, location, unit * 3, st_x, stream, &dx));
+  MDX_TRY(to_device(ke, location, unit, st_k, stream, &dk));
+  MDX_TRY(to_device(pe, location, unit, st_p, stream, &dp));
+  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
+  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  if (dtype == MDX_F32)
+    hipLaunchKernelGGL(energy_weighted_kernel<float>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const float *>(dx), static_cast<const float *>(dk),
+                       static_cast<const float *>(dp), n_atoms, n_frames,
+                       plan.atoms_per_chunk, partial.as<double>());
+  else
+    hipLaunchKernelGGL(energy_weighted_kernel<double>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const double *>(dx), static_cast<const double *>(dk),
+                       static_cast<const double *>(dp), n_atoms, n_frames,
+                       plan.atoms_per_chunk, partial.as<double>());
+  MDX_HIP(hipGetLastError());
+  MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,
                  accumulate, stream));
   MDX_HIP(hipStreamSynchronize(stream));
   return MDX_OK;

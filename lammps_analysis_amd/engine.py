@@ -301,6 +301,25 @@ def thermal_flux(stress: ArrayLike, vel: ArrayLike, ke: ArrayLike, pe: ArrayLike
     return out
 
 
+def energy_weighted_sum(x: ArrayLike, ke: ArrayLike, pe: ArrayLike,
+                        out: Optional[np.ndarray] = None, accumulate: bool = False):
+    """``out[t, :] (+)= sum_a x[a, t, :] * (ke[a, t] + pe[a, t])`` in float64."""
+    infos = [_as_input(a) for a in (x, ke, pe)]
+    if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
+        raise ValueError("all inputs must share dtype and location")
+    n_atoms, n_frames = infos[0][3][0], infos[0][3][1]
+    for info, shp in zip(infos, [(n_atoms, n_frames, 3), (n_atoms, n_frames, 1),
+                                 (n_atoms, n_frames, 1)]):
+        if tuple(info[3]) != shp:
+            raise ValueError(f"expected shape {shp}, got {info[3]}")
+    out = _out_buffer(out, (n_frames, 3), accumulate)
+    check(_lib.load().mdx_energy_weighted_sum(infos[0][0], infos[1][0], infos[2][0],
+                                              infos[0][1], infos[0][2], n_atoms, n_frames,
+                                              out.ctypes.data, MDX_HOST,
+                                              1 if accumulate else 0))
+    return out
+
+
 # ------------------------------------------------ angular distribution function
 
 def adf_accumulate(species_positions: Sequence[ArrayLike], box, cutoff: float,

@@ -54,6 +54,11 @@ class RunComputation:
         return self.transformation_wrapper(MomentumFlux)
 
     @property
+    def IntegratedHeatCurrent(self):
+        from ..transformations import IntegratedHeatCurrent
+        return self.transformation_wrapper(IntegratedHeatCurrent)
+
+    @property
     def ThermalFlux(self):
         from ..transformations import ThermalFlux
         return self.transformation_wrapper(ThermalFlux)
@@ -140,6 +145,10 @@ class RunComputation:
     @property
     def GreenKuboDistinctDiffusionCoefficients(self):
         return self._calculator("GreenKuboDistinctDiffusionCoefficients")
+
+    @property
+    def EinsteinHelfandThermalConductivity(self):
+        return self._calculator("EinsteinHelfandThermalConductivity")
 
     @property
     def EinsteinHelfandIonicConductivity(self):

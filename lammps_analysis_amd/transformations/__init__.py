@@ -1,6 +1,7 @@
 """Transformations: the atom reductions that produce the system series the Green-Kubo /
 Einstein-Helfand calculators correlate, and the per-atom coordinate transformations
 (unwrap, wrap, scale, finite-difference velocities).  All run on the GPU."""
+from .integrated_heat_current import IntegratedHeatCurrent
 from .ionic_current import IonicCurrent
 from .momentum_flux import MomentumFlux
 from .scale_coordinates import ScaleCoordinates
@@ -13,7 +14,7 @@ from .unwrap_via_indices import UnwrapViaIndices
 from .velocity_from_positions import VelocityFromPositions
 from .wrap_coordinates import CoordinateWrapper
 
-__all__ = ["IonicCurrent", "MomentumFlux", "ThermalFlux", "TranslationalDipoleMoment",
+__all__ = ["IntegratedHeatCurrent", "IonicCurrent", "MomentumFlux", "ThermalFlux", "TranslationalDipoleMoment",
            "CoordinateUnwrapper", "UnwrapViaIndices", "CoordinateWrapper", "ScaleCoordinates",
            "VelocityFromPositions", "Transformations", "SingleSpeciesTrafo",
            "MultiSpeciesTrafo", "CannotFindPropertyError", "CannotFindTransformationError"]
@@ -24,6 +25,7 @@ __all__ = ["IonicCurrent", "MomentumFlux", "ThermalFlux", "TranslationalDipoleMo
 switcher_transformations = {
     "Translational_Dipole_Moment": "TranslationalDipoleMoment",
     "Ionic_Current": "IonicCurrent",
+    "Integrated_Heat_Current": "IntegratedHeatCurrent",
     "Momentum_Flux": "MomentumFlux",
     "Thermal_Flux": "ThermalFlux",
 }

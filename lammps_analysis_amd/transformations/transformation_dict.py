@@ -2,6 +2,7 @@
 input is missing (mdsuite/transformations/transformation_dict.py:46-62 of the
 reference).  A list is tried in order until one finds its inputs."""
 from ..database.mdsuite_properties import mdsuite_properties as mdp
+from .integrated_heat_current import IntegratedHeatCurrent
 from .ionic_current import IonicCurrent
 from .momentum_flux import MomentumFlux
 from .scale_coordinates import ScaleCoordinates
@@ -13,6 +14,7 @@ from .velocity_from_positions import VelocityFromPositions
 from .wrap_coordinates import CoordinateWrapper
 
 property_to_transformation_dict = {
+    mdp.integrated_heat_current: IntegratedHeatCurrent,
     mdp.ionic_current: IonicCurrent,
     mdp.momentum_flux: MomentumFlux,
     mdp.positions: [ScaleCoordinates, CoordinateWrapper],

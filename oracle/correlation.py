@@ -498,3 +498,14 @@ def einstein_distinct_windows(pos_a: np.ndarray, pos_b: np.ndarray, same_species
             msd = msd - np.mean([msd_operation(x, y) for x, y in zip(win_a, win_b)], axis=0)
         msd_sum += msd
     return msd_sum
+
+
+def integrated_heat_current(positions_by_species, ke_by_species, pe_by_species) -> np.ndarray:
+    """mdsuite/transformations/integrated_heat_current.py:48-60: ``sum_species sum_atoms
+    pos * (ke + pe)``, float64."""
+    out = None
+    for pos, ke, pe in zip(positions_by_species, ke_by_species, pe_by_species):
+        term = np.sum(np.asarray(pos, np.float64)
+                      * (np.asarray(ke, np.float64) + np.asarray(pe, np.float64)), axis=0)
+        out = term if out is None else out + term
+    return out

@@ -258,3 +258,43 @@ def test_kirkwood_buff_runs_its_own_rdf(gpu, tmp_path):
     assert np.all(np.isfinite(kb["kb_integral"]))
     # an ideal gas has g(r) ~ 1: the integral stays small against the sphere volume
     assert abs(kb["kb_integral"][-1]) < 0.2 * 4 / 3 * np.pi * kb["r"][-1] ** 3
+
+
+def test_einstein_helfand_thermal_conductivity(gpu, tmp_path):
+    """Integrated heat current (positions x energies, reduced over atoms on the GPU)
+    and the MSD-based thermal conductivity built on it."""
+    rng = np.random.default_rng(8)
+    box, n_step, D = 18.0, 700, 90
+    data = {}
+    for name, n in (("Na", 20), ("Cl", 14)):
+        data[name] = {
+            mdsuite_properties.unwrapped_positions:
+                np.cumsum(rng.normal(size=(n_step, n, 3)), axis=0) * 0.1,
+            mdsuite_properties.kinetic_energy: rng.random((n_step, n, 1)),
+            mdsuite_properties.potential_energy: -rng.random((n_step, n, 1)) * 2.0,
+        }
+    project = mds.Project(name="eht_proj", storage_path=tmp_path)
+    exp = project.add_experiment("NaCl", timestep=0.002, temperature=1400.0, units="metal")
+    _add(exp, data, n_step, box_l=[box] * 3)
+    res = exp.run.EinsteinHelfandThermalConductivity(data_range=D, plot=False)["System"]
+
+    stored = {k: {p: np.swapaxes(v, 0, 1).astype(np.float32) for p, v in props.items()}
+              for k, props in data.items()}
+    names = list(data)
+    current = orc.integrated_heat_current(
+        [stored[k][mdsuite_properties.unwrapped_positions] for k in names],
+        [stored[k][mdsuite_properties.kinetic_energy] for k in names],
+        [stored[k][mdsuite_properties.potential_energy] for k in names])
+    series = orc.store_as_float32(current)[None]
+    u = mds.units.METAL
+    prefactor = (1 / (box**3 * 1400.0 * u.boltzmann)
+                 * (u.energy / u.length / u.time / u.temperature))
+    starts = orc.window_starts(n_step, D, 1)
+    msd = np.zeros(D)
+    for s in starts:
+        win = series[0, s:s + D].astype(np.float64)
+        msd += prefactor * np.sum((win - win[0]) ** 2, axis=1)
+    msd /= len(starts)
+    assert_close(res["msd"], msd)
+    np.testing.assert_allclose(res["time"], np.arange(D) * 0.002)
+    assert np.isfinite(res["thermal_conductivity"])
