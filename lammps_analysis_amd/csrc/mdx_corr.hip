@@ -734,15 +734,18 @@ __global__ __launch_bounds__(kThreads) void msd_kernel(
   }
 }
 
-// out[i] = scale * sum_b partial[b][i], blocks in index order
+// out[i] = scale * sum_b partial[b][i].  One wave per lag: lane l adds blocks l, l + 64,
+// ... in order, then the 64 partial sums are combined by a fixed butterfly.
 __global__ __launch_bounds__(kThreads) void combine_blocks_kernel(
     const double *__restrict__ partial, int64_t n_blocks, int R, double scale,
     double *__restrict__ out) {
-  const int i = blockIdx.x * kThreads + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   if (i >= R) return;
   double s = 0.0;
-  for (int64_t b = 0; b < n_blocks; ++b) s = s + partial[b * R + i];
-  out[i] = s * scale;
+  for (int64_t b = lane; b < n_blocks; b += 64) s = s + partial[b * R + i];
+  for (int off = 32; off > 0; off >>= 1) s = s + __shfl_xor(s, off);
+  if (lane == 0) out[i] = s * scale;
 }
 
 // ----------------------------------------------------------------- host side
@@ -1325,7 +1328,7 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
     }
     MDX_HIP(hipGetLastError());
     hipLaunchKernelGGL(combine_blocks_kernel,
-                       dim3(static_cast<unsigned>(ceil_div(R, kThreads))), dim3(kThreads), 0,
+                       dim3(static_cast<unsigned>(ceil_div(R, kThreads / 64))), dim3(kThreads), 0,
                        stream, d_partial.as<double>(), n_blocks, R, scale, d_out.as<double>());
     MDX_HIP(hipGetLastError());
     std::vector<double> h(static_cast<size_t>(R));
@@ -1370,7 +1373,7 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
                        series_per_chunk, d_partial.as<double>());
   }
   MDX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(combine_blocks_kernel, dim3(static_cast<unsigned>(ceil_div(R, kThreads))),
+  hipLaunchKernelGGL(combine_blocks_kernel, dim3(static_cast<unsigned>(ceil_div(R, kThreads / 64))),
                      dim3(kThreads), 0, stream, d_partial.as<double>(), n_blocks, R, scale,
                      d_out.as<double>());
   MDX_HIP(hipGetLastError());
