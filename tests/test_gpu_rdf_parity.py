@@ -211,3 +211,17 @@ def test_host_input_is_streamed_in_blocks(gpu, dtype):
     ref = c_oracle.rdf_hist(np.concatenate(pos, 0).astype(np.float32), n_per_species, box,
                             cutoff, nbins)
     np.testing.assert_array_equal(streamed, ref)
+
+
+@pytest.mark.parametrize("literal", [True, False])
+@pytest.mark.parametrize("strict", [True, False])
+def test_cubic_lattice_shell_counts(gpu, literal, strict):
+    """Known answer independent of the oracle: a periodic simple cubic lattice has 6, 12,
+    8, 6, 24, ... neighbours per shell, i.e. exact pair counts per distance."""
+    from test_oracle_reference_pins import _cubic_lattice, lattice_histogram
+    pos, box = _cubic_lattice()
+    cutoff, nbins = np.float32(4.9), 490
+    got = _gpu_hist(gpu, [pos], [len(pos)], box, cutoff, nbins, strict, literal)[0]
+    full = lattice_histogram(nbins, cutoff).astype(np.int64)
+    expected = full - full // 256 if strict else full
+    np.testing.assert_array_equal(got.astype(np.int64), expected)

@@ -271,3 +271,55 @@ def test_adf_oracle_on_a_right_triangle():
         far = [np.array([[[0.0, 0.0, 0.0]], [[x, 0.0, 0.0]], [[0.0, 1.0, 0.0]]],
                         dtype=np.float32)]
         assert ora.adf_batch(far, [50.0] * 3, 3.0, 10, 0)[(0, 0, 0)][1] == triples
+
+
+# ------------------------------------------------ RDF against lattice geometry
+
+def _cubic_lattice(n=8, spacing=1.25):
+    grid = np.arange(n, dtype=np.float32) * np.float32(spacing)
+    pos = np.stack(np.meshgrid(grid, grid, grid, indexing="ij"), axis=-1).reshape(-1, 1, 3)
+    return np.ascontiguousarray(pos), [n * spacing] * 3
+
+
+def lattice_shell_counts(n=8, spacing=1.25, cutoff=4.9):
+    """Pairs per squared lattice distance k = dx^2 + dy^2 + dz^2 (in units of the spacing)
+    of a periodic simple cubic lattice, by enumeration of lattice vectors (every atom
+    sees the same shells)."""
+    shells = {}
+    half = n // 2
+    for dx in range(-half, half + 1):
+        for dy in range(-half, half + 1):
+            for dz in range(-half, half + 1):
+                if (dx, dy, dz) == (0, 0, 0) or half in (abs(dx), abs(dy), abs(dz)):
+                    continue                       # no image ambiguity below the cutoff
+                k = dx * dx + dy * dy + dz * dz
+                if spacing * np.sqrt(k) < cutoff:
+                    shells[k] = shells.get(k, 0) + 1
+    return {k: c * n**3 // 2 for k, c in shells.items()}
+
+
+def lattice_histogram(nbins, cutoff, n=8, spacing=1.25):
+    """Expected RDF counts of the lattice: every shell distance is sqrt of an exactly
+    representable float32, binned by the histogram rule of the reference."""
+    expected = np.zeros(nbins, dtype=np.uint64)
+    step = float(np.float32(cutoff)) / nbins
+    for k, count in lattice_shell_counts(n, spacing, float(cutoff)).items():
+        d = np.sqrt(np.float32(k * spacing * spacing))
+        expected[int(min(float(d) / step, nbins - 1))] += count
+    return expected
+
+
+def test_rdf_oracles_count_the_shells_of_a_cubic_lattice():
+    """The RDF restatement has no reference fixture to lean on; a periodic simple cubic
+    lattice gives exact pair counts per shell (6, 12, 8, 6, 24, ... neighbours)."""
+    pos, box = _cubic_lattice()
+    cutoff, nbins = np.float32(4.9), 490
+    hist = c_oracle.rdf_hist(pos, [len(pos)], box, cutoff, nbins, strict=False)[0]
+    shells = lattice_shell_counts()
+    assert shells[1] == 512 * 6 // 2 and shells[2] == 512 * 12 // 2 and shells[3] == 512 * 8 // 2
+    np.testing.assert_array_equal(hist, lattice_histogram(nbins, cutoff))
+    # the literal NumPy restatement keeps the reference's strict masks, which drop the
+    # first atom of the species: each shell loses that atom's own neighbours
+    strict = orc_rdf.rdf_histograms([pos], ["Ar"], box, cutoff, nbins, rdf_minibatch=64)
+    full = lattice_histogram(nbins, cutoff).astype(np.int64)
+    np.testing.assert_array_equal(strict["Ar_Ar"].astype(np.int64), full - full // 256)
