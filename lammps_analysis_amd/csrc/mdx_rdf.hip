@@ -37,6 +37,8 @@
 // therefore the bins.
 #include <cmath>
 
+#include <cstdlib>
+
 #include "mdx_common.h"
 
 using namespace mdx;
@@ -521,11 +523,16 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
                        h->d_wrapped.as<int32_t>());
     MDX_HIP(hipGetLastError());
   }
-  // frames per block: large enough to amortise the histogram flush, small
-  // enough to keep several thousand blocks in flight
-  int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 8192;
+  // frames per block: large enough to amortise the histogram flush, small enough
+  // that the last round of blocks is short against the launch (a block of 64 frames
+  // runs ~3 ms at 10k atoms; ~40 blocks per compute unit keep the tail below 3 %)
+  int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 65536;
   if (fpg < 1) fpg = 1;
   if (fpg > kMaxFramesPerGroup) fpg = kMaxFramesPerGroup;
+  if (const char *env = getenv("MDX_RDF_FRAMES_PER_GROUP")) {
+    const int v = atoi(env);
+    if (v >= 1 && v <= kMaxFramesPerGroup) fpg = v;
+  }
   dim3 grid(static_cast<unsigned>(h->n_pairs_shard),
             static_cast<unsigned>(ceil_div(nf, fpg)));
   KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
