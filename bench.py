@@ -54,6 +54,9 @@ def parse_args():
                     help="frames of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--gk-frames", type=int, default=100000,
                     help="frames of the Green-Kubo side measurement (0 disables it)")
+    ap.add_argument("--skip-host-input", action="store_true",
+                    help="leave out the host-memory side measurement (counter passes: "
+                         "its 256-frame blocks share a grid with the full-size launch)")
     ap.add_argument("--literal-kernel", action="store_true",
                     help="time the literal-arithmetic kernel instead of the table kernel")
     return ap.parse_args()
@@ -253,7 +256,8 @@ def main() -> None:
                                                   rank)
         if args.gk_frames > 0:
             result["gk_acf"] = gk_side_measurement(engine, args.gk_frames)
-        result["host_input"] = host_input_measurement(engine, fps)
+        if not args.skip_host_input:
+            result["host_input"] = host_input_measurement(engine, fps)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

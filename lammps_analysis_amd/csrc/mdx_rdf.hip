@@ -782,6 +782,10 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   // device tables
   hipStream_t stream;
   MDX_TRY(get_stream(&stream));
+  // The tables below are filled with blocking copies, which are not ordered against
+  // the library's non-blocking stream: a recycled pool block may still be read by
+  // work queued there, so let that work finish first.
+  MDX_HIP(hipStreamSynchronize(stream));
   MDX_TRY(h->d_hist.alloc(sizeof(uint64_t) * static_cast<size_t>(h->n_keys) * nbins));
   MDX_HIP(hipMemsetAsync(h->d_hist.ptr, 0, h->d_hist.bytes, stream));
   MDX_TRY(h->d_slot_species.alloc(sizeof(int32_t) * slot_species.size() + 16));
