@@ -36,7 +36,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxOwned = 16;  // (window, lag pair) items per thread in the ACF kernel
-constexpr int kSlidePer = 8;   // lags per thread in the sliding kernel
+constexpr int kSlidePerMax = 8;  // most lags a thread of the sliding kernel can own
 
 // ------------------------------------------------------------------ staging
 
@@ -338,20 +338,31 @@ __global__ __launch_bounds__(kThreads) void band_combine_kernel(double *__restri
   Q[e] = sum;
 }
 
+// lag_weight[m] = scale / (R - m) (tfp's unbiased estimate) or scale.
+__global__ __launch_bounds__(kThreads) void lag_weight_kernel(double *__restrict__ lag_weight,
+                                                              int R, double scale,
+                                                              int lag_normalise) {
+  const int m = blockIdx.x * kThreads + threadIdx.x;
+  if (m < R) lag_weight[m] = lag_normalise ? scale / static_cast<double>(R - m) : scale;
+}
+
 // One block walks over windows [w0, w1) of the launch.  W[m] = sum_{n < R - m}
 // P(o + n, m) for the window origin o is computed directly for the first window
 // and updated by the 2*ct products that leave and enter for every later one.
 // Outputs as acf_finish_kernel, at block index block_offset + blockIdx.x.
-template <typename Product, int kBlock>
+template <typename Product, int kBlock, int kPer>
 __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
     Product prod, int64_t ct, int64_t win_begin, int64_t n_win, int64_t windows_per_block,
-    int R, double scale, int lag_normalise, double integral_scale,
+    int R, const double *__restrict__ lag_weight, double integral_scale,
     const double *__restrict__ time, int64_t block_offset, double *__restrict__ acf_blk,
     double *__restrict__ mean_blk, double *__restrict__ m2_blk) {
   // A thread owns the lags m = tid + j * kBlock and the integral indices
-  // i0 + j, j < kSlidePer; their running values stay in registers.  LDS holds two
-  // images of the window correlation (so one barrier per window separates writers
-  // from readers) and the wave totals of the scan.
+  // i0 + j, j < kPer.  Four running values per lag stay in registers (window sum,
+  // its total over windows, mean and M2 of the integral): with 8 lags that is half of
+  // the 128 registers a lane of a 1024-thread block has, which is why the per-lag
+  // constants (weight, time step) are read from their tables in every window rather
+  // than kept.  LDS holds two images of the window correlation (so one barrier per
+  // window separates writers from readers) and the wave totals of the scan.
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *cs_base = reinterpret_cast<double *>(lds_raw);  // [2][R]
   double *tot = cs_base + 2 * static_cast<size_t>(R);     // [kBlock / 64]
@@ -360,35 +371,34 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
   const int64_t blk = block_offset + blockIdx.x;
   const int tid = threadIdx.x;
   const int n_int = R - 1;
-  const int seg = (n_int + kBlock - 1) / kBlock;  // <= kSlidePer, checked by the host
+  const int seg = (n_int + kBlock - 1) / kBlock;  // <= kPer, chosen by the host
   const int i0 = min(n_int, tid * seg);
   const int i1 = min(n_int, i0 + seg);
 
-  double W[kSlidePer], acf[kSlidePer], norm[kSlidePer];
-  double mean[kSlidePer], m2[kSlidePer], dt[kSlidePer];
+  double W[kPer], acf[kPer], mean[kPer], m2[kPer];
   const int64_t o0 = (win_begin + w0) * ct;
 #pragma unroll
-  for (int j = 0; j < kSlidePer; ++j) {
+  for (int j = 0; j < kPer; ++j) {
     const int m = tid + j * kBlock;
     acf[j] = 0.0;
     mean[j] = 0.0;
     m2[j] = 0.0;
     W[j] = 0.0;
-    norm[j] = 0.0;
-    dt[j] = 0.0;
     if (m < R) {
-      norm[j] = lag_normalise ? scale / static_cast<double>(R - m) : scale;
       double sum = 0.0;
       for (int n = 0; n < R - m; ++n) sum = sum + prod(o0 + n, m);
       W[j] = sum;
     }
-    if (time != nullptr && i0 + j < i1) dt[j] = time[i0 + j + 1] - time[i0 + j];
   }
   for (int64_t w = w0; w < w1; ++w) {
     const int64_t o_prev = (win_begin + w - 1) * ct;
     double *cs = cs_base + static_cast<size_t>((w - w0) & 1) * R;
+    // an offset the compiler cannot see through keeps the table reads inside the loop
+    int opaque = 0;
+    asm volatile("" : "+s"(opaque));
+    const double *weight = lag_weight + opaque;
 #pragma unroll
-    for (int j = 0; j < kSlidePer; ++j) {
+    for (int j = 0; j < kPer; ++j) {
       const int m = tid + j * kBlock;
       if (m < R) {
         if (w > w0) {
@@ -397,29 +407,26 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
             d = d + (prod(o_prev + (R - m) + n, m) - prod(o_prev + n, m));
           W[j] = W[j] + d;
         }
-        const double c = W[j] * norm[j];
+        const double c = W[j] * weight[m];
         acf[j] = acf[j] + c;
         cs[m] = c * integral_scale;
       }
     }
     if (time == nullptr) continue;  // uniform: no integral requested
+    const double *tm = time + opaque;
     __syncthreads();  // cs complete; the other image was last read two barriers ago
-    double part[kSlidePer];
     double run = 0.0;
 #pragma unroll
-    for (int j = 0; j < kSlidePer; ++j) {
-      part[j] = 0.0;
-      if (i0 + j < i1) {
-        part[j] = dt[j] * (cs[i0 + j + 1] + cs[i0 + j]) / 2.0;
-        run = run + part[j];
-      }
+    for (int j = 0; j < kPer; ++j) {
+      if (i0 + j < i1)
+        run = run + (tm[i0 + j + 1] - tm[i0 + j]) * (cs[i0 + j + 1] + cs[i0 + j]) / 2.0;
     }
     run = block_exclusive_scan<kBlock>(run, tot);
     const double inv_count = 1.0 / static_cast<double>(w - w0 + 1);
 #pragma unroll
-    for (int j = 0; j < kSlidePer; ++j) {
+    for (int j = 0; j < kPer; ++j) {
       if (i0 + j < i1) {
-        run = run + part[j];
+        run = run + (tm[i0 + j + 1] - tm[i0 + j]) * (cs[i0 + j + 1] + cs[i0 + j]) / 2.0;
         const double delta = run - mean[j];
         const double mu = mean[j] + delta * inv_count;
         mean[j] = mu;
@@ -428,12 +435,292 @@ __global__ __launch_bounds__(kBlock) void acf_slide_kernel(
     }
   }
 #pragma unroll
-  for (int j = 0; j < kSlidePer; ++j) {
+  for (int j = 0; j < kPer; ++j) {
     const int m = tid + j * kBlock;
     if (m < R) acf_blk[blk * R + m] = acf[j];
     if (i0 + j < i1) {
       mean_blk[blk * (R - 1) + i0 + j] = mean[j];
       m2_blk[blk * (R - 1) + i0 + j] = m2[j];
+    }
+  }
+}
+
+// ------------------------------------------- ACF, sliding windows in strips
+//
+// The same recurrence for one series, organised so that the per-window prefix sum
+// of the integral does not cost a block-wide scan per window.  A block walks over its
+// windows in strips of kStripWin; within a strip the lags are taken in phases of
+// 64 * kWaves, one 16 x 64 tile (windows x lags) per wave:
+//   pass 1  lane = lag: the products that enter and leave, W, the window correlation
+//           c = W * weight, its total over windows; c goes to the wave's LDS tile;
+//   pass 2  lane = (window, quarter of the tile's lags): sequential prefix of the
+//           trapezoid terms along the lags, J_m = sum_{j<m} c_j g_j + c_m h_m, which is
+//           the cumulative integral I_{m-1}; quarters are joined by three shuffles,
+//           tiles by the row totals every wave posts in LDS (one barrier per phase);
+//   pass 3  lane = lag: sums of (J - ref) and (J - ref)^2 over the strip's windows,
+//           ref = J of the block's first window (keeps the sums small).
+// Per-lag running values live in the block's output rows and two state rows (L2
+// traffic of ten values per lag per 16 windows).  The series is read as float64
+// component planes xs[d * pitch + t - t0].
+
+constexpr int kStripWin = 16;
+constexpr int kTilePitch = 65;  // doubles per tile row: rows land on different banks
+
+__host__ __device__ constexpr size_t strip_lds_bytes(int waves) {
+  return sizeof(double) * (static_cast<size_t>(waves) * kStripWin * kTilePitch +
+                           2 * static_cast<size_t>(waves) * kStripWin);
+}
+
+// Component planes of frames [t0, t0 + t_len): planes[d * pitch + kPlaneFront + i] =
+// x[(t0 + i) * k + d], widened to float64.  The pads before and after a plane (zeroed by
+// the host) let the blocked loads of acf_strip_kernel run past the ends.
+constexpr int kPlaneFront = 2;
+constexpr int kPlaneBack = 126;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void series_planes_kernel(const T *__restrict__ x, int k,
+                                                                 int64_t t0, int64_t t_len,
+                                                                 int64_t pitch,
+                                                                 double *__restrict__ planes) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= t_len * k) return;
+  const int64_t i = e / k;
+  const int d = static_cast<int>(e - i * k);
+  planes[d * pitch + kPlaneFront + i] = static_cast<double>(x[(t0 + i) * k + d]);
+}
+
+// Trapezoid coefficients over the lag times: g[m] = (dt[m-1] + dt[m]) / 2 with the
+// missing neighbour taken as 0, h[m] = dt[m-1] / 2; zero from R up to `padded`.
+__global__ __launch_bounds__(kThreads) void trapezoid_coeff_kernel(
+    const double *__restrict__ time, int R, int padded, double *__restrict__ g,
+    double *__restrict__ h) {
+  const int m = blockIdx.x * kThreads + threadIdx.x;
+  if (m >= padded) return;
+  double gv = 0.0, hv = 0.0;
+  if (m < R) {
+    const double before = m >= 1 ? time[m] - time[m - 1] : 0.0;
+    const double after = m + 1 < R ? time[m + 1] - time[m] : 0.0;
+    gv = (before + after) / 2.0;
+    hv = before / 2.0;
+  }
+  g[m] = gv;
+  h[m] = hv;
+}
+
+template <int K, int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
+    const double *__restrict__ xs_padded, int64_t pitch, int k_runtime, int64_t t0, int64_t ct,
+    int64_t win_begin, int64_t n_win, int64_t windows_per_block, int R,
+    const double *__restrict__ weight, const double *__restrict__ gcoef,
+    const double *__restrict__ hcoef, double integral_scale, int64_t block_offset,
+    double *__restrict__ acf_blk, double *__restrict__ mean_blk, double *__restrict__ m2_blk,
+    double *__restrict__ w_state, double *__restrict__ ref_state) {
+  constexpr int kLagsPerPhase = kWaves * 64;
+  const double *__restrict__ xs = xs_padded + kPlaneFront;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double *tile = reinterpret_cast<double *>(lds_raw) +
+                 static_cast<size_t>(threadIdx.x >> 6) * kStripWin * kTilePitch;
+  double *rowtot = reinterpret_cast<double *>(lds_raw) +
+                   static_cast<size_t>(kWaves) * kStripWin * kTilePitch;  // [2][kWaves][16]
+  const int k = (K > 0) ? K : k_runtime;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t w0 = static_cast<int64_t>(blockIdx.x) * windows_per_block;
+  const int64_t w1 = min(n_win, w0 + windows_per_block);
+  const int64_t blk = block_offset + blockIdx.x;
+  const bool integrate = gcoef != nullptr;
+  const int n_phases = (R + kLagsPerPhase - 1) / kLagsPerPhase;
+  double *acf_b = acf_blk + blk * R;
+  double *mean_b = mean_blk + blk * (R - 1) - 1;  // indexed by lag m >= 1
+  double *m2_b = m2_blk + blk * (R - 1) - 1;
+  double *w_b = w_state + static_cast<int64_t>(blockIdx.x) * R;  // state rows: per launch
+  double *ref_b = ref_state + static_cast<int64_t>(blockIdx.x) * R;
+
+  // first window of the block, directly: eight products at a time per lag; the
+  // wave runs to the trip count of its first lane and masks the rest
+  {
+    const double *a = xs + ((win_begin + w0) * ct - t0);
+    for (int m = tid; m < R; m += kLagsPerPhase) {
+      const int trips = R - (m - lane);  // of lane 0 of this wave
+      const int mine = R - m;
+      double sum = 0.0;
+      for (int n0 = 0; n0 < trips; n0 += 8) {
+        double p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = 0.0;
+#pragma unroll
+        for (int d = 0; d < k; ++d) {
+          const double *u = a + d * pitch + n0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) p[i] = fma(u[i], u[i + m], p[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (n0 + i < mine) sum = sum + p[i];
+      }
+      w_b[m] = sum;
+      acf_b[m] = 0.0;
+      if (integrate && m >= 1) {
+        mean_b[m] = 0.0;
+        m2_b[m] = 0.0;
+      }
+    }
+  }
+
+  const int w_i = lane & (kStripWin - 1);  // pass 2: this lane's window of the strip
+  const int quarter = lane >> 4;           // and its 16 lags of the tile
+  int parity = 0;
+  for (int64_t ws = w0; ws < w1; ws += kStripWin) {
+    const int rows = static_cast<int>(min<int64_t>(kStripWin, w1 - ws));
+    double carry = 0.0;  // integral terms of window ws + w_i over the lags of earlier phases
+    for (int p = 0; p < n_phases; ++p) {
+      const int m_base = p * kLagsPerPhase + wave * 64;
+      const bool tile_ok = m_base < R;  // wave-uniform
+      const int m = m_base + lane;
+      const bool lag_ok = m < R;
+      if (tile_ok) {
+        double W = 0.0, acf = 0.0, wt = 0.0;
+        if (lag_ok) {
+          W = w_b[m];
+          acf = acf_b[m];
+          wt = weight[m];
+        }
+        if (ct == 1) {
+          // origins advance by one frame per window: a lag needs kSub consecutive
+          // values of each operand for kSub windows (the operands shared by all lags
+          // sit in scalar registers, which bounds kSub)
+          constexpr int kSub = 4;
+          const double *leave0 = xs + (win_begin + ws - 1 - t0);
+          const int ma = lag_ok ? m : 0;  // lanes past the last lag read valid addresses
+          for (int sub = 0; sub < rows; sub += kSub) {
+            double in[kSub], out[kSub];
+#pragma unroll
+            for (int i = 0; i < kSub; ++i) {
+              in[i] = 0.0;
+              out[i] = 0.0;
+            }
+            const double *leave = leave0 + sub;
+            const double *enter = leave + R;
+#pragma unroll
+            for (int d = 0; d < k; ++d) {
+              const double *lv = leave + d * pitch;
+              const double *en = enter + d * pitch;
+#pragma unroll
+              for (int i = 0; i < kSub; ++i) {
+                in[i] = fma(en[i - ma], en[i], in[i]);
+                out[i] = fma(lv[i], lv[i + ma], out[i]);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < kSub; ++i) {
+              const int row = sub + i;
+              if (row < rows) {
+                if (lag_ok && ws + row > w0) W = W + (in[i] - out[i]);
+                const double c = W * wt;
+                acf = acf + c;
+                if (integrate) tile[row * kTilePitch + lane] = c * integral_scale;
+              }
+            }
+          }
+        } else {
+          for (int i = 0; i < rows; ++i) {
+            const int64_t w = ws + i;
+            if (w > w0 && lag_ok) {
+              const double *leave = xs + ((win_begin + w - 1) * ct - t0);
+              const double *enter = leave + R;
+              double delta = 0.0;
+              for (int64_t n = 0; n < ct; ++n) {
+                double in = 0.0, out = 0.0;
+#pragma unroll
+                for (int d = 0; d < k; ++d) {
+                  in = fma(enter[d * pitch + n - m], enter[d * pitch + n], in);
+                  out = fma(leave[d * pitch + n], leave[d * pitch + n + m], out);
+                }
+                delta = delta + (in - out);
+              }
+              W = W + delta;
+            }
+            const double c = W * wt;
+            acf = acf + c;
+            if (integrate) tile[i * kTilePitch + lane] = c * integral_scale;
+          }
+        }
+        if (lag_ok) {
+          w_b[m] = W;
+          acf_b[m] = acf;
+        }
+      }
+      if (!integrate) continue;  // uniform
+
+      // pass 2: the tile is private to the wave, whose LDS accesses execute in order
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double J[16];
+      double run = 0.0;
+      if (tile_ok) {
+        const double *row = tile + w_i * kTilePitch + quarter * 16;
+        const double *g = gcoef + m_base + quarter * 16;
+        const double *h = hcoef + m_base + quarter * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const double c = row[j];
+          J[j] = fma(c, h[j], run);
+          run = fma(c, g[j], run);
+        }
+      }
+      const double q1 = __shfl_up(run, 16);
+      const double q2 = __shfl_up(run, 32);
+      const double q3 = __shfl_up(run, 48);
+      double offset = 0.0;
+      if (quarter >= 3) offset = offset + q3;
+      if (quarter >= 2) offset = offset + q2;
+      if (quarter >= 1) offset = offset + q1;
+      double *posted = rowtot + static_cast<size_t>(parity) * kWaves * kStripWin;
+      if (quarter == 3) posted[wave * kStripWin + w_i] = tile_ok ? offset + run : 0.0;
+      __syncthreads();
+      double before = carry;
+      double total = carry;
+#pragma unroll
+      for (int v = 0; v < kWaves; ++v) {
+        if (v == wave) before = total;
+        total = total + posted[v * kStripWin + w_i];
+      }
+      carry = total;
+      parity ^= 1;
+      if (tile_ok) {
+        double *row = tile + w_i * kTilePitch + quarter * 16;
+        const double base = before + offset;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) row[j] = J[j] + base;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+
+      // pass 3
+      if (lag_ok && m >= 1) {
+        double s1 = mean_b[m], s2 = m2_b[m];
+        double ref = (ws == w0) ? tile[lane] : ref_b[m];
+        for (int i = 0; i < rows; ++i) {
+          const double d = tile[i * kTilePitch + lane] - ref;
+          s1 = s1 + d;
+          s2 = fma(d, d, s2);
+        }
+        mean_b[m] = s1;
+        m2_b[m] = s2;
+        if (ws == w0) ref_b[m] = ref;
+      }
+    }
+  }
+
+  if (integrate) {
+    const double count = static_cast<double>(w1 - w0);
+    for (int m = tid; m < R; m += kLagsPerPhase) {
+      if (m < 1) continue;
+      const double s1 = mean_b[m], s2 = m2_b[m];
+      const double spread = s2 - s1 * s1 / count;
+      mean_b[m] = ref_b[m] + s1 / count;
+      m2_b[m] = spread > 0.0 ? spread : 0.0;
     }
   }
 }
@@ -831,9 +1118,15 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
   const bool cross = job.cross_a != nullptr;
   {
     // four lags per thread at most before the block grows to 1024 threads
+    // one series straight from the caller's array: the strip kernel
+    const bool strip = !band && !cross && n_series == 1;
+    const int strip_waves = R > 256 ? 8 : (R > 128 ? 4 : 2);
     const int slide_block = (R > 1024) ? 1024 : 256;
     const size_t lds_s = sizeof(double) * (2 * static_cast<size_t>(R) + slide_block / 64);
-    static_assert(8192 <= kSlidePer * 1024, "lags per thread");
+    static_assert(8192 <= kSlidePerMax * 1024, "lags per thread");
+    // lags per thread, rounded up to an instantiated count
+    const int per_need = static_cast<int>(ceil_div(R, slide_block));
+    const int slide_per = slide_block == 256 ? 4 : (per_need <= 3 ? 3 : per_need <= 5 ? 5 : 8);
     // windows per block: enough to amortise the directly computed first window
     // (R/2 products per lag against 2*ct per slide), few enough to fill the chip
     // and to bound the drift of the running sums
@@ -848,6 +1141,16 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
       const int64_t cap = R > 512 ? R : 512;
       if (wpb > cap) wpb = cap;
       if (wpb < 1) wpb = 1;
+      if (strip) {
+        // whole rounds of resident blocks (two per compute unit), whole strips
+        const int64_t slots = 512;
+        int64_t blocks = ceil_div(windows, wpb);
+        if (blocks > slots) {
+          blocks = blocks / slots * slots;
+          wpb = ceil_div(windows, blocks);
+        }
+        wpb = ceil_div(wpb, kStripWin) * kStripWin;
+      }
       return wpb;
     };
     // window segments: the whole range at once from the series, or as many windows
@@ -887,6 +1190,14 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
     const int64_t seg_frames = (seg_windows - 1) * correlation_time + R;
     if (band) MDX_TRY(d_C.alloc(sizeof(double) * n_chunks * seg_frames * R));
     const double *d_time_ptr = job.d_time;
+    // per-lag weights; the buffer goes back to the pool when this function returns and
+    // can only be handed to later work of the same stream
+    DeviceBuffer d_weight, d_planes, d_coef, d_state;
+    MDX_TRY(d_weight.alloc(sizeof(double) * R));
+    hipLaunchKernelGGL(lag_weight_kernel, dim3(static_cast<unsigned>(ceil_div(R, kThreads))),
+                       dim3(kThreads), 0, stream, d_weight.as<double>(), R, scale,
+                       lag_normalise);
+    MDX_HIP(hipGetLastError());
 
     int64_t block_offset = 0;
     for (int64_t ws = 0; ws < n_win; ws += seg_windows) {
@@ -947,23 +1258,27 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
         }
       }
       KernelTimer timer(MDX_SLOT_ACF_FINISH, stream);
-#define MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, BLOCK)                                      \
+#define MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, BLOCK, PER)                                 \
   do {                                                                                       \
     MDX_HIP(hipFuncSetAttribute(                                                             \
-        reinterpret_cast<const void *>(acf_slide_kernel<PRODUCT_TYPE, BLOCK>),               \
+        reinterpret_cast<const void *>(acf_slide_kernel<PRODUCT_TYPE, BLOCK, PER>),          \
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_s)));               \
-    hipLaunchKernelGGL((acf_slide_kernel<PRODUCT_TYPE, BLOCK>),                              \
+    hipLaunchKernelGGL((acf_slide_kernel<PRODUCT_TYPE, BLOCK, PER>),                         \
                        dim3(static_cast<unsigned>(n_blocks)), dim3(BLOCK), lds_s, stream,    \
-                       PRODUCT, correlation_time, win_begin + ws, nw, wpb, R, scale,         \
-                       lag_normalise, integral_scale, d_time_ptr, block_offset,              \
+                       PRODUCT, correlation_time, win_begin + ws, nw, wpb, R,                \
+                       d_weight.as<double>(), integral_scale, d_time_ptr, block_offset,      \
                        d_acf.as<double>(), d_mean.as<double>(), d_m2.as<double>());          \
   } while (0)
 #define MDX_LAUNCH_SLIDE(PRODUCT_TYPE, PRODUCT)                                              \
   do {                                                                                       \
-    if (slide_block == 1024)                                                                 \
-      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 1024);                                       \
+    if (slide_block == 256)                                                                  \
+      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 256, 4);                                     \
+    else if (slide_per == 3)                                                                 \
+      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 1024, 3);                                    \
+    else if (slide_per == 5)                                                                 \
+      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 1024, 5);                                    \
     else                                                                                     \
-      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 256);                                        \
+      MDX_LAUNCH_SLIDE_B(PRODUCT_TYPE, PRODUCT, 1024, 8);                                    \
   } while (0)
 #define MDX_LAUNCH_SLIDE_SERIES(TYPE)                                                        \
   do {                                                                                       \
@@ -982,7 +1297,66 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
       MDX_LAUNCH_SLIDE(P, prod);                                                             \
     }                                                                                        \
   } while (0)
-      if (cross) {
+      if (strip) {
+        const int lags_per_phase = strip_waves * 64;
+        const int padded = static_cast<int>(ceil_div(R, lags_per_phase)) * lags_per_phase;
+        const int64_t plane_pitch = t_len + kPlaneFront + kPlaneBack;
+        MDX_TRY(d_planes.alloc(sizeof(double) * plane_pitch * k));
+        MDX_HIP(hipMemsetAsync(d_planes.ptr, 0, sizeof(double) * plane_pitch * k, stream));
+        MDX_TRY(d_state.alloc(sizeof(double) * 2 * n_blocks * R));
+        const double *g = nullptr, *h = nullptr;
+        if (d_time_ptr != nullptr) {
+          MDX_TRY(d_coef.alloc(sizeof(double) * 2 * padded));
+          hipLaunchKernelGGL(trapezoid_coeff_kernel,
+                             dim3(static_cast<unsigned>(ceil_div(padded, kThreads))),
+                             dim3(kThreads), 0, stream, d_time_ptr, R, padded,
+                             d_coef.as<double>(), d_coef.as<double>() + padded);
+          MDX_HIP(hipGetLastError());
+          g = d_coef.as<double>();
+          h = g + padded;
+        }
+        if (dtype == MDX_F32) {
+          hipLaunchKernelGGL(series_planes_kernel<float>,
+                             dim3(static_cast<unsigned>(ceil_div(t_len * k, kThreads))),
+                             dim3(kThreads), 0, stream, static_cast<const float *>(dx), k, t0,
+                             t_len, plane_pitch, d_planes.as<double>());
+        } else {
+          hipLaunchKernelGGL(series_planes_kernel<double>,
+                             dim3(static_cast<unsigned>(ceil_div(t_len * k, kThreads))),
+                             dim3(kThreads), 0, stream, static_cast<const double *>(dx), k, t0,
+                             t_len, plane_pitch, d_planes.as<double>());
+        }
+        MDX_HIP(hipGetLastError());
+#define MDX_LAUNCH_STRIP(KK, WAVES)                                                          \
+  do {                                                                                       \
+    const size_t lds_t = strip_lds_bytes(WAVES);                                             \
+    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_strip_kernel<KK, WAVES>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                                static_cast<int>(lds_t)));                                   \
+    hipLaunchKernelGGL((acf_strip_kernel<KK, WAVES>), dim3(static_cast<unsigned>(n_blocks)), \
+                       dim3(WAVES * 64), lds_t, stream, d_planes.as<double>(), plane_pitch,  \
+                       k, t0,                                                                \
+                       correlation_time, win_begin + ws, nw, wpb, R, d_weight.as<double>(),  \
+                       g, h, integral_scale, block_offset, d_acf.as<double>(),               \
+                       d_mean.as<double>(), d_m2.as<double>(), d_state.as<double>(),         \
+                       d_state.as<double>() + n_blocks * R);                                 \
+  } while (0)
+#define MDX_LAUNCH_STRIP_K(WAVES)                                                            \
+  do {                                                                                       \
+    if (k == 3)                                                                              \
+      MDX_LAUNCH_STRIP(3, WAVES);                                                            \
+    else                                                                                     \
+      MDX_LAUNCH_STRIP(0, WAVES);                                                            \
+  } while (0)
+        if (strip_waves == 8)
+          MDX_LAUNCH_STRIP_K(8);
+        else if (strip_waves == 4)
+          MDX_LAUNCH_STRIP_K(4);
+        else
+          MDX_LAUNCH_STRIP_K(2);
+#undef MDX_LAUNCH_STRIP_K
+#undef MDX_LAUNCH_STRIP
+      } else if (cross) {
         const double *table = band ? d_C.as<double>() : nullptr;
         if (dtype == MDX_F32) {
           using P = DistinctProduct<float>;
