@@ -337,7 +337,7 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
     def chain():
         cur = engine.weighted_atom_sum(vel_na, scalar_weight=1.0)
         cur = engine.weighted_atom_sum(vel_cl, scalar_weight=-1.0, out=cur, accumulate=True)
-        series = cur.astype(np.float32).astype(np.float64)[None]
+        series = cur.astype(np.float32)[None]  # what a calculator loads from the store
         acf, mom = engine.acf_windows(series, 1, 0, n_win, tau, time=time_axis)
         return cur, acf
 

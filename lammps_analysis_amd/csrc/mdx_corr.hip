@@ -472,7 +472,7 @@ __host__ __device__ constexpr size_t strip_lds_bytes(int waves) {
 }
 
 // Component planes of frames [t0, t0 + t_len): planes[d * pitch + kPlaneFront + i] =
-// x[(t0 + i) * k + d], widened to float64.  The pads before and after a plane (zeroed by
+// x[(t0 + i) * k + d], in the input's precision.  The pads before and after a plane (zeroed by
 // the host) let the blocked loads of acf_strip_kernel run past the ends.
 constexpr int kPlaneFront = 2;
 constexpr int kPlaneBack = 126;
@@ -481,12 +481,12 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void series_planes_kernel(const T *__restrict__ x, int k,
                                                                  int64_t t0, int64_t t_len,
                                                                  int64_t pitch,
-                                                                 double *__restrict__ planes) {
+                                                                 T *__restrict__ planes) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (e >= t_len * k) return;
   const int64_t i = e / k;
   const int d = static_cast<int>(e - i * k);
-  planes[d * pitch + kPlaneFront + i] = static_cast<double>(x[(t0 + i) * k + d]);
+  planes[d * pitch + kPlaneFront + i] = x[(t0 + i) * k + d];
 }
 
 // Trapezoid coefficients over the lag times: g[m] = (dt[m-1] + dt[m]) / 2 with the
@@ -507,16 +507,16 @@ __global__ __launch_bounds__(kThreads) void trapezoid_coeff_kernel(
   h[m] = hv;
 }
 
-template <int K, int kWaves>
+template <typename TP, int K, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
-    const double *__restrict__ xs_padded, int64_t pitch, int k_runtime, int64_t t0, int64_t ct,
+    const TP *__restrict__ xs_padded, int64_t pitch, int k_runtime, int64_t t0, int64_t ct,
     int64_t win_begin, int64_t n_win, int64_t windows_per_block, int R,
     const double *__restrict__ weight, const double *__restrict__ gcoef,
     const double *__restrict__ hcoef, double integral_scale, int64_t block_offset,
     double *__restrict__ acf_blk, double *__restrict__ mean_blk, double *__restrict__ m2_blk,
     double *__restrict__ w_state, double *__restrict__ ref_state) {
   constexpr int kLagsPerPhase = kWaves * 64;
-  const double *__restrict__ xs = xs_padded + kPlaneFront;
+  const TP *__restrict__ xs = xs_padded + kPlaneFront;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *tile = reinterpret_cast<double *>(lds_raw) +
                  static_cast<size_t>(threadIdx.x >> 6) * kStripWin * kTilePitch;
@@ -540,10 +540,11 @@ __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
   // first window of the block, directly: eight products at a time per lag; the
   // wave runs to the trip count of its first lane and masks the rest
   {
-    const double *a = xs + ((win_begin + w0) * ct - t0);
+    const TP *a = xs + ((win_begin + w0) * ct - t0);
     for (int m = tid; m < R; m += kLagsPerPhase) {
       const int trips = R - (m - lane);  // of lane 0 of this wave
       const int mine = R - m;
+      const int common = max(0, trips - 63) & ~7;  // every lane of the wave runs this far
       double sum = 0.0;
       for (int n0 = 0; n0 < trips; n0 += 8) {
         double p[8];
@@ -551,13 +552,19 @@ __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
         for (int i = 0; i < 8; ++i) p[i] = 0.0;
 #pragma unroll
         for (int d = 0; d < k; ++d) {
-          const double *u = a + d * pitch + n0;
+          const TP *u = a + d * pitch + n0;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) p[i] = fma(u[i], u[i + m], p[i]);
+          for (int i = 0; i < 8; ++i)
+            p[i] = fma(static_cast<double>(u[i]), static_cast<double>(u[i + m]), p[i]);
         }
+        if (n0 < common) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (n0 + i < mine) sum = sum + p[i];
+          for (int i = 0; i < 8; ++i) sum = sum + p[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (n0 + i < mine) sum = sum + p[i];
+        }
       }
       w_b[m] = sum;
       acf_b[m] = 0.0;
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
           // values of each operand for kSub windows (the operands shared by all lags
           // sit in scalar registers, which bounds kSub)
           constexpr int kSub = 4;
-          const double *leave0 = xs + (win_begin + ws - 1 - t0);
+          const TP *leave0 = xs + (win_begin + ws - 1 - t0);
           const int ma = lag_ok ? m : 0;  // lanes past the last lag read valid addresses
           for (int sub = 0; sub < rows; sub += kSub) {
             double in[kSub], out[kSub];
@@ -600,26 +607,37 @@ __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
               in[i] = 0.0;
               out[i] = 0.0;
             }
-            const double *leave = leave0 + sub;
-            const double *enter = leave + R;
+            const TP *leave = leave0 + sub;
+            const TP *enter = leave + R;
 #pragma unroll
             for (int d = 0; d < k; ++d) {
-              const double *lv = leave + d * pitch;
-              const double *en = enter + d * pitch;
+              const TP *lv = leave + d * pitch;
+              const TP *en = enter + d * pitch;
 #pragma unroll
               for (int i = 0; i < kSub; ++i) {
-                in[i] = fma(en[i - ma], en[i], in[i]);
-                out[i] = fma(lv[i], lv[i + ma], out[i]);
+                in[i] = fma(static_cast<double>(en[i - ma]), static_cast<double>(en[i]), in[i]);
+                out[i] = fma(static_cast<double>(lv[i]), static_cast<double>(lv[i + ma]), out[i]);
               }
             }
+            // lanes past the last lag carry a meaningless W; their weight is zero
+            if (sub + kSub <= rows && (ws > w0 || sub > 0)) {
 #pragma unroll
-            for (int i = 0; i < kSub; ++i) {
-              const int row = sub + i;
-              if (row < rows) {
-                if (lag_ok && ws + row > w0) W = W + (in[i] - out[i]);
+              for (int i = 0; i < kSub; ++i) {
+                W = W + (in[i] - out[i]);
                 const double c = W * wt;
                 acf = acf + c;
-                if (integrate) tile[row * kTilePitch + lane] = c * integral_scale;
+                if (integrate) tile[(sub + i) * kTilePitch + lane] = c * integral_scale;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < kSub; ++i) {
+                const int row = sub + i;
+                if (row < rows) {
+                  if (ws + row > w0) W = W + (in[i] - out[i]);
+                  const double c = W * wt;
+                  acf = acf + c;
+                  if (integrate) tile[row * kTilePitch + lane] = c * integral_scale;
+                }
               }
             }
           }
@@ -627,15 +645,17 @@ __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
           for (int i = 0; i < rows; ++i) {
             const int64_t w = ws + i;
             if (w > w0 && lag_ok) {
-              const double *leave = xs + ((win_begin + w - 1) * ct - t0);
-              const double *enter = leave + R;
+              const TP *leave = xs + ((win_begin + w - 1) * ct - t0);
+              const TP *enter = leave + R;
               double delta = 0.0;
               for (int64_t n = 0; n < ct; ++n) {
                 double in = 0.0, out = 0.0;
 #pragma unroll
                 for (int d = 0; d < k; ++d) {
-                  in = fma(enter[d * pitch + n - m], enter[d * pitch + n], in);
-                  out = fma(leave[d * pitch + n], leave[d * pitch + n + m], out);
+                  in = fma(static_cast<double>(enter[d * pitch + n - m]),
+                           static_cast<double>(enter[d * pitch + n]), in);
+                  out = fma(static_cast<double>(leave[d * pitch + n]),
+                            static_cast<double>(leave[d * pitch + n + m]), out);
                 }
                 delta = delta + (in - out);
               }
@@ -1301,8 +1321,9 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
         const int lags_per_phase = strip_waves * 64;
         const int padded = static_cast<int>(ceil_div(R, lags_per_phase)) * lags_per_phase;
         const int64_t plane_pitch = t_len + kPlaneFront + kPlaneBack;
-        MDX_TRY(d_planes.alloc(sizeof(double) * plane_pitch * k));
-        MDX_HIP(hipMemsetAsync(d_planes.ptr, 0, sizeof(double) * plane_pitch * k, stream));
+        const size_t plane_bytes = dtype_size(dtype) * static_cast<size_t>(plane_pitch) * k;
+        MDX_TRY(d_planes.alloc(plane_bytes));
+        MDX_HIP(hipMemsetAsync(d_planes.ptr, 0, plane_bytes, stream));
         MDX_TRY(d_state.alloc(sizeof(double) * 2 * n_blocks * R));
         const double *g = nullptr, *h = nullptr;
         if (d_time_ptr != nullptr) {
@@ -1315,46 +1336,45 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
           g = d_coef.as<double>();
           h = g + padded;
         }
-        if (dtype == MDX_F32) {
-          hipLaunchKernelGGL(series_planes_kernel<float>,
-                             dim3(static_cast<unsigned>(ceil_div(t_len * k, kThreads))),
-                             dim3(kThreads), 0, stream, static_cast<const float *>(dx), k, t0,
-                             t_len, plane_pitch, d_planes.as<double>());
-        } else {
-          hipLaunchKernelGGL(series_planes_kernel<double>,
-                             dim3(static_cast<unsigned>(ceil_div(t_len * k, kThreads))),
-                             dim3(kThreads), 0, stream, static_cast<const double *>(dx), k, t0,
-                             t_len, plane_pitch, d_planes.as<double>());
-        }
-        MDX_HIP(hipGetLastError());
-#define MDX_LAUNCH_STRIP(KK, WAVES)                                                          \
+#define MDX_LAUNCH_STRIP(TYPE, KK, WAVES)                                                    \
   do {                                                                                       \
     const size_t lds_t = strip_lds_bytes(WAVES);                                             \
-    MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(acf_strip_kernel<KK, WAVES>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize,                  \
-                                static_cast<int>(lds_t)));                                   \
-    hipLaunchKernelGGL((acf_strip_kernel<KK, WAVES>), dim3(static_cast<unsigned>(n_blocks)), \
-                       dim3(WAVES * 64), lds_t, stream, d_planes.as<double>(), plane_pitch,  \
-                       k, t0,                                                                \
-                       correlation_time, win_begin + ws, nw, wpb, R, d_weight.as<double>(),  \
-                       g, h, integral_scale, block_offset, d_acf.as<double>(),               \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(acf_strip_kernel<TYPE, KK, WAVES>),                   \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_t)));               \
+    hipLaunchKernelGGL((acf_strip_kernel<TYPE, KK, WAVES>),                                  \
+                       dim3(static_cast<unsigned>(n_blocks)), dim3(WAVES * 64), lds_t,       \
+                       stream, d_planes.as<TYPE>(), plane_pitch, k, t0, correlation_time,    \
+                       win_begin + ws, nw, wpb, R, d_weight.as<double>(), g, h,              \
+                       integral_scale, block_offset, d_acf.as<double>(),                     \
                        d_mean.as<double>(), d_m2.as<double>(), d_state.as<double>(),         \
                        d_state.as<double>() + n_blocks * R);                                 \
   } while (0)
-#define MDX_LAUNCH_STRIP_K(WAVES)                                                            \
+#define MDX_LAUNCH_STRIP_T(TYPE)                                                             \
   do {                                                                                       \
-    if (k == 3)                                                                              \
-      MDX_LAUNCH_STRIP(3, WAVES);                                                            \
+    hipLaunchKernelGGL(series_planes_kernel<TYPE>,                                           \
+                       dim3(static_cast<unsigned>(ceil_div(t_len * k, kThreads))),           \
+                       dim3(kThreads), 0, stream, static_cast<const TYPE *>(dx), k, t0,      \
+                       t_len, plane_pitch, d_planes.as<TYPE>());                             \
+    MDX_HIP(hipGetLastError());                                                              \
+    if (k == 3 && strip_waves == 8)                                                          \
+      MDX_LAUNCH_STRIP(TYPE, 3, 8);                                                          \
+    else if (k == 3 && strip_waves == 4)                                                     \
+      MDX_LAUNCH_STRIP(TYPE, 3, 4);                                                          \
+    else if (k == 3)                                                                         \
+      MDX_LAUNCH_STRIP(TYPE, 3, 2);                                                          \
+    else if (strip_waves == 8)                                                               \
+      MDX_LAUNCH_STRIP(TYPE, 0, 8);                                                          \
+    else if (strip_waves == 4)                                                               \
+      MDX_LAUNCH_STRIP(TYPE, 0, 4);                                                          \
     else                                                                                     \
-      MDX_LAUNCH_STRIP(0, WAVES);                                                            \
+      MDX_LAUNCH_STRIP(TYPE, 0, 2);                                                          \
   } while (0)
-        if (strip_waves == 8)
-          MDX_LAUNCH_STRIP_K(8);
-        else if (strip_waves == 4)
-          MDX_LAUNCH_STRIP_K(4);
+        if (dtype == MDX_F32)
+          MDX_LAUNCH_STRIP_T(float);
         else
-          MDX_LAUNCH_STRIP_K(2);
-#undef MDX_LAUNCH_STRIP_K
+          MDX_LAUNCH_STRIP_T(double);
+#undef MDX_LAUNCH_STRIP_T
 #undef MDX_LAUNCH_STRIP
       } else if (cross) {
         const double *table = band ? d_C.as<double>() : nullptr;
