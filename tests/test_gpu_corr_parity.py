@@ -188,6 +188,37 @@ def test_acf_sliding_sums_do_not_drift(gpu):
     assert_close(acf, c_oracle.acf_windows(x.astype(np.float64), 1, 0, n_win, tau), rtol=1e-10)
 
 
+@pytest.mark.parametrize("T,D,k,ct,begin,dtype", [
+    (700, 5, 3, 1, 0, np.float32),       # fewer lags than one tile, ragged last strip
+    (900, 130, 3, 1, 17, np.float64),    # four waves, windows start inside the series
+    (2500, 257, 3, 1, 3, np.float32),    # eight waves, last tile one lag wide
+    (3000, 700, 3, 1, 0, np.float64),    # two lag phases
+    (1500, 96, 3, 5, 2, np.float32),     # several frames enter and leave per window
+    (1200, 200, 1, 1, 0, np.float32),    # scalar series
+    (1100, 150, 6, 2, 1, np.float64),    # six components
+])
+def test_acf_single_series_strip_kernel(gpu, T, D, k, ct, begin, dtype):
+    """One series: windows in strips of 16, lags in tiles of 64, the integral's prefix
+    sums joined across tiles and phases; every edge of that tiling."""
+    rng = np.random.default_rng(18)
+    x = (np.cumsum(rng.normal(size=(1, T, k)), axis=1) * 0.02
+         + rng.normal(size=(1, T, k))).astype(dtype)
+    tau = np.arange(D)
+    time = np.cumsum(np.concatenate([[0.0], 0.01 + 0.005 * rng.random(D - 1)]))  # uneven
+    end = (T - D) // ct
+    acf, mom = gpu.acf_windows(x, ct, begin, end, tau, scale=1.5, integral_scale=0.25,
+                               time=time)
+    x64 = x.astype(np.float64)
+    ref_pw = 1.5 * _per_window_reference(x64, ct, begin, end, tau)
+    assert_close(acf, ref_pw.sum(axis=0))
+    sig = np.array([cumulative_trapezoid(0.25 * r, x=time) for r in ref_pw])
+    assert mom.n == end - begin
+    assert_close(mom.mean, sig.mean(axis=0))
+    assert_close(mom.std(), np.std(sig, axis=0))
+    acf_only, _ = gpu.acf_windows(x, ct, begin, end, tau, scale=1.5)
+    np.testing.assert_array_equal(acf_only, acf)
+
+
 def test_acf_rejects_windows_beyond_the_batch(gpu):
     x = np.zeros((1, 100, 3))
     with pytest.raises(ValueError):
