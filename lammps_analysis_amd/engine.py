@@ -82,7 +82,22 @@ class DeviceArray:
         n = self.nbytes // 4
         check(_lib.load().mdx_fill_uniform_f32(self.ptr, n, int(seed), float(lo), float(hi)))
 
+    def reshape(self, shape) -> "DeviceArray":
+        """The same memory under another shape; the result does not own it and keeps
+        this array alive."""
+        shape = tuple(int(s) for s in shape)
+        if int(np.prod(shape, dtype=np.int64)) * self.dtype.itemsize != self.nbytes:
+            raise ValueError(f"cannot reshape {self.shape} to {shape}")
+        view = object.__new__(DeviceArray)
+        view.shape, view.dtype, view.nbytes, view.ptr = shape, self.dtype, self.nbytes, self.ptr
+        view._base = self
+        return view
+
     def free(self) -> None:
+        if getattr(self, "_base", None) is not None:
+            self.ptr = None
+            self._base = None
+            return
         if getattr(self, "ptr", None):
             _lib.load().mdx_free(self.ptr)
             self.ptr = None
@@ -252,14 +267,23 @@ def _out_buffer(out: Optional[np.ndarray], shape, accumulate: bool) -> np.ndarra
 
 
 def weighted_atom_sum(x: ArrayLike, scalar_weight: float = 1.0,
-                      weights: Optional[np.ndarray] = None, out: Optional[np.ndarray] = None,
-                      accumulate: bool = False) -> np.ndarray:
-    """``out[t, c] (+)= sum_a w_a * x[a, t, c]`` in float64; x is ``[N, T, k]``."""
+                      weights: Optional[np.ndarray] = None, out=None,
+                      accumulate: bool = False):
+    """``out[t, c] (+)= sum_a w_a * x[a, t, c]`` in float64; x is ``[N, T, k]``.
+
+    ``out`` may be a float64 ``DeviceArray`` of shape ``(T, k)``: the series then stays
+    in device memory (for a following ``map_coordinates`` / ``acf_windows``)."""
     ptr, dt, loc, shape, keep = _as_input(x)
     if len(shape) != 3:
         raise ValueError("x must have shape (n_atoms, n_frames, k)")
     n_atoms, n_frames, k = shape
-    out = _out_buffer(out, (n_frames, k), accumulate)
+    if isinstance(out, DeviceArray):
+        if out.dtype != np.float64 or out.shape != (n_frames, k):
+            raise ValueError(f"out must be a float64 device array of shape {(n_frames, k)}")
+        out_ptr, out_loc = out.ptr, MDX_DEVICE
+    else:
+        out = _out_buffer(out, (n_frames, k), accumulate)
+        out_ptr, out_loc = out.ctypes.data, MDX_HOST
     wptr = None
     if weights is not None:
         w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
@@ -267,7 +291,7 @@ def weighted_atom_sum(x: ArrayLike, scalar_weight: float = 1.0,
             raise ValueError("weights must have one entry per atom")
         wptr = w.ctypes.data_as(_lib.c_f64_p)
     check(_lib.load().mdx_weighted_atom_sum(ptr, dt, loc, n_atoms, n_frames, k, wptr,
-                                            float(scalar_weight), out.ctypes.data, MDX_HOST,
+                                            float(scalar_weight), out_ptr, out_loc,
                                             1 if accumulate else 0))
     return out
 

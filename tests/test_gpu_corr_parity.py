@@ -58,6 +58,33 @@ def test_weighted_atom_sum_per_atom_weights_and_device_input(gpu):
     np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
 
 
+def test_series_can_stay_on_the_device(gpu):
+    """Atom sums into a device array, float32 rounding by the scale map, correlation of the
+    device-resident series: identical to the route through host arrays."""
+    rng = np.random.default_rng(19)
+    a = rng.normal(size=(50, 700, 3)).astype(np.float32)
+    b = rng.normal(size=(30, 700, 3)).astype(np.float32)
+    tau = np.arange(40)
+    time = tau * 0.5
+    host = gpu.weighted_atom_sum(a, scalar_weight=1.0)
+    host = gpu.weighted_atom_sum(b, scalar_weight=-2.0, out=host, accumulate=True)
+    series = host.astype(np.float32)[None]
+    acf_h, mom_h = gpu.acf_windows(series, 1, 0, 660, tau, time=time)
+    cur = gpu.DeviceArray((700, 3), np.float64)
+    gpu.weighted_atom_sum(a, scalar_weight=1.0, out=cur)
+    gpu.weighted_atom_sum(gpu.DeviceArray.from_numpy(b), scalar_weight=-2.0, out=cur,
+                          accumulate=True)
+    np.testing.assert_array_equal(cur.to_numpy(), host)
+    rounded = gpu.DeviceArray((1, 700, 3), np.float32)
+    gpu.map_coordinates(gpu.MAP_SCALE, cur.reshape((1, 700, 3)), [1.0, 1.0, 1.0], out=rounded)
+    np.testing.assert_array_equal(rounded.to_numpy(), series)
+    acf_d, mom_d = gpu.acf_windows(rounded, 1, 0, 660, tau, time=time)
+    np.testing.assert_array_equal(acf_d, acf_h)
+    np.testing.assert_array_equal(mom_d.m2, mom_h.m2)
+    with pytest.raises(ValueError):
+        cur.reshape((2, 700, 3))
+
+
 def test_momentum_and_thermal_flux(gpu):
     rng = np.random.default_rng(9)
     n, t = 41, 97
