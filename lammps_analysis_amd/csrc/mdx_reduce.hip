@@ -23,17 +23,20 @@ constexpr int kUnroll = 8;
 
 template <typename T, int VEC>
 struct VecLoad;
+// every element is read exactly once: loads bypass the caches' retention (non-temporal)
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 template <>
 struct VecLoad<float, 4> {
   static __device__ __forceinline__ void load(const float *p, double (&v)[4]) {
-    const float4 t = *reinterpret_cast<const float4 *>(p);
+    const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
 };
 template <>
 struct VecLoad<double, 2> {
   static __device__ __forceinline__ void load(const double *p, double (&v)[2]) {
-    const double2 t = *reinterpret_cast<const double2 *>(p);
+    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
     v[0] = t.x; v[1] = t.y;
   }
 };
