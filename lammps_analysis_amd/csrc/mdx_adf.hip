@@ -59,12 +59,10 @@ __global__ __launch_bounds__(kThreads) void adf_gather_kernel(
 }
 
 // A block covers 256 atoms i and a chunk of atoms j (grid.z); counts[frame][i] must be
-// zero at launch.
-// kStore == false: counts[frame][i] += neighbours found in the chunk.
-// kStore == true : the same, and every neighbour takes the next free slot of
-//                  nbr_index / nbr_vec [frame][i][capacity] (vec = unit vector, length);
-//                  the order of a list therefore varies from run to run.
-template <bool kStore>
+// zero at launch.  Every neighbour found raises counts[frame][i] and takes the next free
+// slot of nbr_index / nbr_vec [frame][i][capacity] (vec = unit vector, length) if there
+// is one; the host checks the largest count against the capacity afterwards.  The order of
+// a list varies from run to run.
 __global__ __launch_bounds__(kThreads) void adf_neighbour_kernel(
     const float *__restrict__ X, int64_t n_atoms, int64_t n_pad, AdfBox p, float cutoff,
     int capacity, int64_t j_chunk, int32_t *__restrict__ counts,
@@ -81,7 +79,6 @@ __global__ __launch_bounds__(kThreads) void adf_neighbour_kernel(
   const _Float16 cut16 = static_cast<_Float16>(cutoff);
   const float inv_box[3] = {1.0f / p.box[0], 1.0f / p.box[1], 1.0f / p.box[2]};
   const float s_far = (cutoff * 1.002f) * (cutoff * 1.002f);
-  int n = 0;
   const int64_t base = (f * n_atoms + i) * capacity;
   // j_chunk is a multiple of 4: four j atoms per wave-uniform 16-byte load
   const int64_t j_begin = static_cast<int64_t>(blockIdx.z) * j_chunk;
@@ -115,19 +112,14 @@ __global__ __launch_bounds__(kThreads) void adf_neighbour_kernel(
       // (padding) fails the comparison
       const bool inside = active && (d16 != static_cast<_Float16>(0.0f)) && (d16 < cut16);
       if (inside) {
-        if (kStore) {
-          const int slot = atomicAdd(&counts[f * n_atoms + i], 1);
-          if (slot < capacity) {
-            nbr_index[base + slot] = static_cast<int32_t>(j0 + u);
-            nbr_vec[base + slot] = make_float4(rx / d, ry / d, rz / d, d);
-          }
-        } else {
-          ++n;
+        const int slot = atomicAdd(&counts[f * n_atoms + i], 1);
+        if (slot < capacity) {
+          nbr_index[base + slot] = static_cast<int32_t>(j0 + u);
+          nbr_vec[base + slot] = make_float4(rx / d, ry / d, rz / d, d);
         }
       }
     }
   }
-  if (!kStore && active && n > 0) atomicAdd(&counts[f * n_atoms + i], n);
 }
 
 // x^p: repeated multiplication for the integer powers 0..8 (within 2 ulp of powf, and
@@ -335,9 +327,20 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(lds)));
 
-  // frames per block of work: packed image and counts bounded to ~256 MiB
+  // Neighbour lists are written in one pass into slots sized from the mean density
+  // (twice the expected neighbourhood plus a margin); a frame block whose largest
+  // neighbourhood does not fit is searched again with the exact size.
   const int64_t n_pad = (n_atoms + 3) / 4 * 4;
+  const double reach = static_cast<double>(cutoff) * 1.002;
+  const double expected = static_cast<double>(n_atoms) /
+                          (static_cast<double>(box[0]) * box[1] * box[2]) * 4.18879020478639 *
+                          reach * reach * reach;
+  int64_t guess = static_cast<int64_t>(2.0 * expected) + 32;
+  if (guess > n_atoms) guess = n_atoms;
+  // frames per block of work: packed image bounded to ~256 MiB, lists to ~8 GiB
   int64_t chunk = (int64_t(256) << 20) / (n_pad * 16);
+  const int64_t list_chunk = (int64_t(8) << 30) / (n_atoms * guess * 20);
+  if (chunk > list_chunk) chunk = list_chunk;
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 65535) chunk = 65535;
@@ -371,32 +374,35 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
     j_chunks = ceil_div(n_pad, j_chunk);
     const dim3 ngrid(atom_blocks, static_cast<unsigned>(nf), static_cast<unsigned>(j_chunks));
     const size_t count_bytes = sizeof(int32_t) * n_atoms * nf;
-    MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
-    hipLaunchKernelGGL(adf_neighbour_kernel<false>, ngrid, dim3(kThreads), 0, stream,
-                       d_X.as<float>(), n_atoms, n_pad, p, cutoff, 0, j_chunk,
-                       d_counts.as<int32_t>(), static_cast<int32_t *>(nullptr),
-                       static_cast<float4 *>(nullptr));
-    MDX_HIP(hipGetLastError());
-    MDX_HIP(hipMemsetAsync(d_max.ptr, 0, sizeof(int32_t), stream));
-    hipLaunchKernelGGL(adf_max_kernel, dim3(256), dim3(kThreads), 0, stream,
-                       d_counts.as<int32_t>(), n_atoms * nf, d_max.as<int32_t>());
-    MDX_HIP(hipGetLastError());
-    int32_t capacity = 0;
-    MDX_HIP(hipMemcpyAsync(&capacity, d_max.ptr, sizeof(int32_t), hipMemcpyDeviceToHost,
-                           stream));
-    MDX_HIP(hipStreamSynchronize(stream));
-    if (capacity < 2) continue;  // no atom has two neighbours: no triplets
-    const size_t slots = static_cast<size_t>(n_atoms) * nf * capacity;
-    MDX_REQUIRE(slots * 20 <= (size_t(64) << 30),
-                "neighbour lists need %zu bytes (largest neighbourhood %d atoms)", slots * 20,
-                capacity);
-    MDX_TRY(d_index.reserve(sizeof(int32_t) * slots));
-    MDX_TRY(d_vec.reserve(sizeof(float4) * slots));
-    MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
-    hipLaunchKernelGGL(adf_neighbour_kernel<true>, ngrid, dim3(kThreads), 0, stream,
-                       d_X.as<float>(), n_atoms, n_pad, p, cutoff, capacity, j_chunk,
-                       d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>());
-    MDX_HIP(hipGetLastError());
+    int32_t capacity = static_cast<int32_t>(guess);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      const size_t slots = static_cast<size_t>(n_atoms) * nf * capacity;
+      MDX_REQUIRE(slots * 20 <= (size_t(64) << 30),
+                  "neighbour lists need %zu bytes (largest neighbourhood %d atoms)", slots * 20,
+                  capacity);
+      MDX_TRY(d_index.reserve(sizeof(int32_t) * slots));
+      MDX_TRY(d_vec.reserve(sizeof(float4) * slots));
+      MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
+      hipLaunchKernelGGL(adf_neighbour_kernel, ngrid, dim3(kThreads), 0, stream,
+                         d_X.as<float>(), n_atoms, n_pad, p, cutoff, capacity, j_chunk,
+                         d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>());
+      MDX_HIP(hipGetLastError());
+      MDX_HIP(hipMemsetAsync(d_max.ptr, 0, sizeof(int32_t), stream));
+      hipLaunchKernelGGL(adf_max_kernel, dim3(256), dim3(kThreads), 0, stream,
+                         d_counts.as<int32_t>(), n_atoms * nf, d_max.as<int32_t>());
+      MDX_HIP(hipGetLastError());
+      int32_t largest = 0;
+      MDX_HIP(hipMemcpyAsync(&largest, d_max.ptr, sizeof(int32_t), hipMemcpyDeviceToHost,
+                             stream));
+      MDX_HIP(hipStreamSynchronize(stream));
+      if (largest <= capacity) {
+        if (largest < 2) capacity = 0;  // no atom has two neighbours: no triplets
+        break;
+      }
+      MDX_REQUIRE(attempt == 0, "neighbour count changed between two searches of a frame block");
+      capacity = largest;
+    }
+    if (capacity < 2) continue;
     const int atoms_per_block = 64;
     const dim3 tgrid(static_cast<unsigned>(ceil_div(n_atoms, atoms_per_block)),
                      static_cast<unsigned>(nf));

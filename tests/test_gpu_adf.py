@@ -52,6 +52,30 @@ def test_adf_matches_oracle(gpu, sizes, n_frames, box, cutoff, nbins, power):
         np.testing.assert_allclose(got, ref_hist, rtol=0, atol=1e-4 * ref_hist.max())
 
 
+def test_adf_cluster_denser_than_the_mean_density(gpu):
+    """Neighbour slots are sized from the mean density; a droplet in a large box overflows
+    them, and the frame block is searched again with the exact size."""
+    rng = np.random.default_rng(53)
+    box, cutoff, nbins = [60.0, 60.0, 60.0], 4.0, 60
+    pos = [(30.0 + 2.5 * rng.normal(size=(n, 2, 3))).astype(np.float32) for n in (45, 40)]
+    first = np.concatenate([p[:, 0] for p in pos]).astype(np.float64)
+    dist = np.linalg.norm(first[:, None] - first[None], axis=-1)
+    assert ((dist < cutoff).sum(axis=1) - 1).max() > 40  # mean density predicts < 1
+    pos[0][:, 1] += 29.0  # second frame: the droplet straddles the periodic boundary
+    pos[1][:, 1] += 29.0
+    pos = [np.mod(p, 60.0).astype(np.float32) for p in pos]
+    edges = _edges(nbins)
+    hist, triples = gpu.adf_accumulate(pos, box, cutoff, edges, norm_power=4)
+    ref = ora.adf_batch(pos, box, cutoff, nbins, 4)
+    combos = list(itertools.combinations_with_replacement(range(2), 3))
+    for c, key in enumerate(combos):
+        ref_hist, ref_count, ref_weight = ref[key]
+        assert int(triples[c]) == ref_count, key
+        np.testing.assert_allclose(hist[c].sum(), ref_weight, rtol=1e-6)
+        np.testing.assert_allclose(_density(hist[c], edges), ref_hist, rtol=0,
+                                   atol=1e-4 * ref_hist.max())
+
+
 def test_adf_frame_selection_device_input_and_float64(gpu):
     rng = np.random.default_rng(52)
     sizes, box, cutoff, nbins = [25, 30], [8.0, 8.0, 8.0], 3.2, 80
