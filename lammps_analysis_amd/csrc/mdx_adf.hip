@@ -5,8 +5,9 @@
 //   adf_gather_kernel     species arrays [atoms][frames][3] -> X[frame][component][atom]
 //   adf_neighbour_kernel  thread = atom i, loop over every j: literal float32 minimum
 //                         image, distance, cutoff test in float16 as the reference
-//                         does; first run counts the neighbours, second run stores
-//                         them (index, unit vector, length) in per-atom lists;
+//                         does; neighbours (index, unit vector, length) go into
+//                         per-atom lists sized from the mean density, a second run
+//                         with the exact size follows only if a list overflowed;
 //                         grid.z splits the j loop so that few frames fill the chip
 //   adf_triplet_kernel    wave = atom i, lanes stride over the ordered neighbour pairs:
 //                         angle = acos(clamp(u_ij . u_ik)), weight = 1 / (|r_ij| |r_ik|)^p,
