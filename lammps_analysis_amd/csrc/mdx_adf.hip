@@ -123,6 +123,141 @@ __global__ __launch_bounds__(kThreads) void adf_neighbour_kernel(
   }
 }
 
+// ------------------------------------------------------------------ cell lists
+//
+// For systems of a few thousand atoms and more, and cutoffs below a third of the box,
+// the pair search runs over a grid of cells whose edges are at least 1.01 cutoffs: an
+// atom's neighbours sit in its own and the 26 surrounding cells (periodic).  Every pair
+// it finds goes through the same arithmetic as in adf_neighbour_kernel, and every pair
+// that kernel would accept lies in those cells, so the lists hold the same neighbours.
+
+struct AdfCells {
+  int nc[3];
+  int n_cells;
+};
+
+__device__ __forceinline__ int cell_coordinate(float x, float box, int nc) {
+  float u = x / box;
+  u = u - floorf(u);  // position folded into [0, 1]
+  const int c = static_cast<int>(u * static_cast<float>(nc));
+  return min(max(c, 0), nc - 1);
+}
+
+// cell_of[f][i], rank_in_cell[f][i] (arrival order) and cell_count[f][cell]; the counts
+// must be zero at launch.
+__global__ __launch_bounds__(kThreads) void adf_cell_assign_kernel(
+    const float *__restrict__ X, int64_t n_atoms, int64_t n_pad, int nf, AdfBox p, AdfCells g,
+    int32_t *__restrict__ cell_of, int32_t *__restrict__ rank_in_cell,
+    int32_t *__restrict__ cell_count) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= n_atoms * nf) return;
+  const int64_t f = e / n_atoms;
+  const int64_t i = e - f * n_atoms;
+  const float *x = X + f * 3 * n_pad;
+  const int cx = cell_coordinate(x[i], p.box[0], g.nc[0]);
+  const int cy = cell_coordinate(x[n_pad + i], p.box[1], g.nc[1]);
+  const int cz = cell_coordinate(x[2 * n_pad + i], p.box[2], g.nc[2]);
+  const int c = (cx * g.nc[1] + cy) * g.nc[2] + cz;
+  cell_of[e] = c;
+  rank_in_cell[e] = atomicAdd(&cell_count[f * g.n_cells + c], 1);
+}
+
+// cell_start[f][0 .. n_cells] = exclusive prefix sums of cell_count[f][.]; one block
+// per frame, a thread sums a contiguous run of cells.
+__global__ __launch_bounds__(kThreads) void adf_cell_scan_kernel(
+    const int32_t *__restrict__ cell_count, int n_cells, int32_t *__restrict__ cell_start) {
+  __shared__ int32_t run_total[kThreads];
+  const int64_t f = blockIdx.x;
+  const int32_t *count = cell_count + f * n_cells;
+  int32_t *start = cell_start + f * (n_cells + 1);
+  const int per = (n_cells + kThreads - 1) / kThreads;
+  const int c0 = min(n_cells, static_cast<int>(threadIdx.x) * per);
+  const int c1 = min(n_cells, c0 + per);
+  int32_t sum = 0;
+  for (int c = c0; c < c1; ++c) sum += count[c];
+  run_total[threadIdx.x] = sum;
+  __syncthreads();
+  int32_t before = 0;
+  for (int t = 0; t < static_cast<int>(threadIdx.x); ++t) before += run_total[t];
+  for (int c = c0; c < c1; ++c) {
+    start[c] = before;
+    before += count[c];
+  }
+  if (threadIdx.x == kThreads - 1) start[n_cells] = before;
+}
+
+// sorted[f][slot] = (x, y, z, atom index as bits), atoms of one cell adjacent.
+__global__ __launch_bounds__(kThreads) void adf_cell_scatter_kernel(
+    const float *__restrict__ X, int64_t n_atoms, int64_t n_pad, int nf, int n_cells,
+    const int32_t *__restrict__ cell_of, const int32_t *__restrict__ rank_in_cell,
+    const int32_t *__restrict__ cell_start, float4 *__restrict__ sorted) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (e >= n_atoms * nf) return;
+  const int64_t f = e / n_atoms;
+  const int64_t i = e - f * n_atoms;
+  const float *x = X + f * 3 * n_pad;
+  const int slot = cell_start[f * (n_cells + 1) + cell_of[e]] + rank_in_cell[e];
+  sorted[f * n_atoms + slot] =
+      make_float4(x[i], x[n_pad + i], x[2 * n_pad + i], __int_as_float(static_cast<int>(i)));
+}
+
+// Thread = one atom (in cell order), loop over the atoms of its 27 cells.  Outputs as
+// adf_neighbour_kernel, except that counts need not be zeroed.
+__global__ __launch_bounds__(kThreads) void adf_neighbour_cells_kernel(
+    const float4 *__restrict__ sorted, int64_t n_atoms, AdfBox p, AdfCells g, float cutoff,
+    int capacity, const int32_t *__restrict__ cell_of, const int32_t *__restrict__ cell_start,
+    int32_t *__restrict__ counts, int32_t *__restrict__ nbr_index,
+    float4 *__restrict__ nbr_vec) {
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (s >= n_atoms) return;
+  const int64_t f = blockIdx.y;
+  const float4 *atoms = sorted + f * n_atoms;
+  const int32_t *start = cell_start + f * (g.n_cells + 1);
+  const float4 me = atoms[s];
+  const int i = __float_as_int(me.w);
+  const int c = cell_of[f * n_atoms + i];
+  const int cz = c % g.nc[2];
+  const int cy = (c / g.nc[2]) % g.nc[1];
+  const int cx = c / (g.nc[2] * g.nc[1]);
+  const _Float16 cut16 = static_cast<_Float16>(cutoff);
+  const float inv_box[3] = {1.0f / p.box[0], 1.0f / p.box[1], 1.0f / p.box[2]};
+  const float s_far = (cutoff * 1.002f) * (cutoff * 1.002f);
+  const int64_t base = (f * n_atoms + i) * capacity;
+  int n = 0;
+  for (int dx = -1; dx <= 1; ++dx) {
+    const int nx = (cx + dx + g.nc[0]) % g.nc[0];
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int ny = (cy + dy + g.nc[1]) % g.nc[1];
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int nz = (cz + dz + g.nc[2]) % g.nc[2];
+        const int cell = (nx * g.nc[1] + ny) * g.nc[2] + nz;
+        const int j_end = start[cell + 1];
+        for (int j = start[cell]; j < j_end; ++j) {
+          const float4 other = atoms[j];
+          float rx = me.x - other.x;
+          float ry = me.y - other.y;
+          float rz = me.z - other.z;
+          rx = rx - exact_rint_quotient(rx, p.box[0], inv_box[0]) * p.box[0];
+          ry = ry - exact_rint_quotient(ry, p.box[1], inv_box[1]) * p.box[1];
+          rz = rz - exact_rint_quotient(rz, p.box[2], inv_box[2]) * p.box[2];
+          const float sq = (rx * rx + ry * ry) + rz * rz;
+          if (!(sq < s_far)) continue;
+          const float d = sqrtf(sq);
+          const _Float16 d16 = static_cast<_Float16>(d);
+          if ((d16 != static_cast<_Float16>(0.0f)) && (d16 < cut16)) {
+            if (n < capacity) {
+              nbr_index[base + n] = __float_as_int(other.w);
+              nbr_vec[base + n] = make_float4(rx / d, ry / d, rz / d, d);
+            }
+            ++n;
+          }
+        }
+      }
+    }
+  }
+  counts[f * n_atoms + i] = n;
+}
+
 // x^p: repeated multiplication for the integer powers 0..8 (within 2 ulp of powf, and
 // far cheaper), powf otherwise.
 __device__ __forceinline__ float small_power(float x, float p, int int_power) {
@@ -345,7 +480,34 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 65535) chunk = 65535;
+  // cell grid: edges of at least 1.01 cutoffs, at least three cells along every axis
+  // (otherwise a periodic neighbour cell would be visited twice), enough atoms to pay
+  // for the sort
+  AdfCells cells{{1, 1, 1}, 1};
+  bool use_cells = true;
+  for (int c = 0; c < 3; ++c) {
+    const double fit = static_cast<double>(box[c]) / (static_cast<double>(cutoff) * 1.01);
+    cells.nc[c] = fit > 128.0 ? 128 : static_cast<int>(fit);
+    if (cells.nc[c] < 3) use_cells = false;
+  }
+  cells.n_cells = cells.nc[0] * cells.nc[1] * cells.nc[2];
+  int64_t cell_min_atoms = 2048;
+  if (const char *env = getenv("MDX_ADF_CELL_MIN_ATOMS")) cell_min_atoms = atoll(env);
+  if (n_atoms < cell_min_atoms) use_cells = false;
+  if (use_cells) {
+    // count and start tables bounded to ~1 GiB per block of frames
+    const int64_t cell_chunk = (int64_t(1) << 30) / (static_cast<int64_t>(cells.n_cells) * 8);
+    if (chunk > cell_chunk) chunk = cell_chunk < 1 ? 1 : cell_chunk;
+  }
   DeviceBuffer d_X, d_counts, d_max, d_index, d_vec;
+  DeviceBuffer d_cell_of, d_rank, d_cell_count, d_cell_start, d_sorted;
+  if (use_cells) {
+    MDX_TRY(d_cell_of.alloc(sizeof(int32_t) * n_atoms * chunk));
+    MDX_TRY(d_rank.alloc(sizeof(int32_t) * n_atoms * chunk));
+    MDX_TRY(d_cell_count.alloc(sizeof(int32_t) * cells.n_cells * chunk));
+    MDX_TRY(d_cell_start.alloc(sizeof(int32_t) * (cells.n_cells + 1) * chunk));
+    MDX_TRY(d_sorted.alloc(sizeof(float4) * n_atoms * chunk));
+  }
   MDX_TRY(d_X.alloc(sizeof(float) * 3 * n_pad * chunk));
   MDX_TRY(d_counts.alloc(sizeof(int32_t) * n_atoms * chunk));
   MDX_TRY(d_max.alloc(sizeof(int32_t)));
@@ -375,6 +537,23 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
     j_chunks = ceil_div(n_pad, j_chunk);
     const dim3 ngrid(atom_blocks, static_cast<unsigned>(nf), static_cast<unsigned>(j_chunks));
     const size_t count_bytes = sizeof(int32_t) * n_atoms * nf;
+    if (use_cells) {
+      const dim3 agrid(static_cast<unsigned>(ceil_div(n_atoms * nf, kThreads)));
+      MDX_HIP(hipMemsetAsync(d_cell_count.ptr, 0, sizeof(int32_t) * cells.n_cells * nf, stream));
+      hipLaunchKernelGGL(adf_cell_assign_kernel, agrid, dim3(kThreads), 0, stream,
+                         d_X.as<float>(), n_atoms, n_pad, nf, p, cells, d_cell_of.as<int32_t>(),
+                         d_rank.as<int32_t>(), d_cell_count.as<int32_t>());
+      MDX_HIP(hipGetLastError());
+      hipLaunchKernelGGL(adf_cell_scan_kernel, dim3(static_cast<unsigned>(nf)), dim3(kThreads),
+                         0, stream, d_cell_count.as<int32_t>(), cells.n_cells,
+                         d_cell_start.as<int32_t>());
+      MDX_HIP(hipGetLastError());
+      hipLaunchKernelGGL(adf_cell_scatter_kernel, agrid, dim3(kThreads), 0, stream,
+                         d_X.as<float>(), n_atoms, n_pad, nf, cells.n_cells,
+                         d_cell_of.as<int32_t>(), d_rank.as<int32_t>(),
+                         d_cell_start.as<int32_t>(), d_sorted.as<float4>());
+      MDX_HIP(hipGetLastError());
+    }
     int32_t capacity = static_cast<int32_t>(guess);
     for (int attempt = 0; attempt < 2; ++attempt) {
       const size_t slots = static_cast<size_t>(n_atoms) * nf * capacity;
@@ -383,10 +562,18 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
                   capacity);
       MDX_TRY(d_index.reserve(sizeof(int32_t) * slots));
       MDX_TRY(d_vec.reserve(sizeof(float4) * slots));
-      MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
-      hipLaunchKernelGGL(adf_neighbour_kernel, ngrid, dim3(kThreads), 0, stream,
-                         d_X.as<float>(), n_atoms, n_pad, p, cutoff, capacity, j_chunk,
-                         d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>());
+      if (use_cells) {
+        hipLaunchKernelGGL(adf_neighbour_cells_kernel,
+                           dim3(atom_blocks, static_cast<unsigned>(nf)), dim3(kThreads), 0,
+                           stream, d_sorted.as<float4>(), n_atoms, p, cells, cutoff, capacity,
+                           d_cell_of.as<int32_t>(), d_cell_start.as<int32_t>(),
+                           d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>());
+      } else {
+        MDX_HIP(hipMemsetAsync(d_counts.ptr, 0, count_bytes, stream));
+        hipLaunchKernelGGL(adf_neighbour_kernel, ngrid, dim3(kThreads), 0, stream,
+                           d_X.as<float>(), n_atoms, n_pad, p, cutoff, capacity, j_chunk,
+                           d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>());
+      }
       MDX_HIP(hipGetLastError());
       MDX_HIP(hipMemsetAsync(d_max.ptr, 0, sizeof(int32_t), stream));
       hipLaunchKernelGGL(adf_max_kernel, dim3(256), dim3(kThreads), 0, stream,

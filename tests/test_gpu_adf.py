@@ -76,6 +76,33 @@ def test_adf_cluster_denser_than_the_mean_density(gpu):
                                    atol=1e-4 * ref_hist.max())
 
 
+@pytest.mark.parametrize("sizes,box,cutoff,spread", [
+    ([150, 130], [10.0, 11.0, 12.5], 3.0, 0.0),      # three cells along every axis
+    ([400], [21.0, 16.0, 30.0], 2.9, 0.0),           # 7 x 5 x 10 cells
+    ([120, 90, 60], [13.0, 13.0, 13.0], 3.1, 40.0),  # coordinates far outside the box
+])
+def test_adf_cell_list_search(gpu, monkeypatch, sizes, box, cutoff, spread):
+    """The cell-list pair search (normally chosen from 2048 atoms on) finds the neighbours
+    the all-pairs search finds: identical triple counts, and agreement with the oracle."""
+    rng = np.random.default_rng(54)
+    nbins, power, n_frames = 45, 4, 3
+    pos = [((rng.random((n, n_frames, 3)) - 0.5 * (spread > 0)) * (np.array(box) + spread))
+           .astype(np.float32) for n in sizes]
+    edges = _edges(nbins)
+    monkeypatch.setenv("MDX_ADF_CELL_MIN_ATOMS", "1")
+    hist_c, triples_c = gpu.adf_accumulate(pos, box, cutoff, edges, norm_power=power)
+    monkeypatch.setenv("MDX_ADF_CELL_MIN_ATOMS", "1000000")
+    hist_a, triples_a = gpu.adf_accumulate(pos, box, cutoff, edges, norm_power=power)
+    np.testing.assert_array_equal(triples_c, triples_a)
+    np.testing.assert_allclose(hist_c, hist_a, rtol=1e-9, atol=1e-9 * hist_a.max())
+    ref = ora.adf_batch(pos, box, cutoff, nbins, power)
+    combos = list(itertools.combinations_with_replacement(range(len(sizes)), 3))
+    for c, key in enumerate(combos):
+        ref_hist, ref_count, ref_weight = ref[key]
+        assert int(triples_c[c]) == ref_count, key
+        np.testing.assert_allclose(hist_c[c].sum(), ref_weight, rtol=1e-6)
+
+
 def test_adf_frame_selection_device_input_and_float64(gpu):
     rng = np.random.default_rng(52)
     sizes, box, cutoff, nbins = [25, 30], [8.0, 8.0, 8.0], 3.2, 80
