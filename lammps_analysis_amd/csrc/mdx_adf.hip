@@ -9,11 +9,14 @@
 //                         per-atom lists sized from the mean density, a second run
 //                         with the exact size follows only if a list overflowed;
 //                         grid.z splits the j loop so that few frames fill the chip
-//   adf_triplet_kernel    wave = atom i, lanes stride over the ordered neighbour pairs:
-//                         angle = acos(clamp(u_ij . u_ik)), weight = 1 / (|r_ij| |r_ik|)^p,
-//                         float64 LDS histograms per species triple, flushed once
+//   adf_triplet_kernel    wave = atom i, its list staged in LDS, lanes stride over the
+//                         unordered neighbour pairs (each stands for the reference's two
+//                         ordered ones): angle = acos(clamp(u_ij . u_ik)),
+//                         weight = 1 / (|r_ij| |r_ik|)^p, float64 LDS histograms per
+//                         species triple, flushed once
+// Larger systems replace the all-pairs loop by a cell list (see "cell lists" below).
 //
-// The pair search is the same N^2 loop as the radial distribution function; with
+// The all-pairs search is the same N^2 loop as the radial distribution function; with
 // cutoffs of a few Angstrom a frame has ~N * n^2 triplets (n ~ 30 neighbours), far
 // less work.  Compiled with -ffp-contract=off and correctly rounded divide / sqrt,
 // so the vectors, lengths and unit vectors are bit-identical to a float32 NumPy
@@ -276,23 +279,41 @@ __device__ __forceinline__ float small_power(float x, float p, int int_power) {
 // hist[combo][bin] (float64) and triples[combo] accumulate over the launch.
 // LDS: double hist[n_combos * nbins] | double edges[nbins + 1] |
 //      uint32 count[n_combos][kCountCopies] (one copy per lane pair: the lanes of a wave
-//      mostly count the same species triple)
+//      mostly count the same species triple) |
+//      per wave: float4 vec[stage] | int32 species[stage] (kStaged only)
+//
+// The reference walks over ordered neighbour pairs (j, k) and keeps those whose species
+// triple (i, j, k) is in non-decreasing order.  (j, k) and (k, j) share angle and weight,
+// so a wave evaluates every unordered pair once — enumerated as (a, a + s mod n), s = 1 ..
+// n/2, which needs no square root — and books it once if only one order qualifies, twice if
+// both do (equal species).  kStaged: the atom's list is first copied into LDS (it is read
+// n times); lists longer than the staging area are read from global memory instead.
+template <bool kStaged>
 __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
     const int32_t *__restrict__ counts, const int32_t *__restrict__ nbr_index,
     const float4 *__restrict__ nbr_vec, const int32_t *__restrict__ atom_species,
     const int32_t *__restrict__ combo_of, int n_species, int n_combos, int64_t n_atoms,
-    int capacity, int atoms_per_block, int nbins, const double *__restrict__ g_edges,
-    float norm_power, double *__restrict__ g_hist, unsigned long long *__restrict__ g_triples) {
+    int capacity, int stage, int atoms_per_block, int nbins,
+    const double *__restrict__ g_edges, float norm_power, double *__restrict__ g_hist,
+    unsigned long long *__restrict__ g_triples) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *hist = reinterpret_cast<double *>(lds_raw);
   double *edges = hist + static_cast<size_t>(n_combos) * nbins;
   uint32_t *count = reinterpret_cast<uint32_t *>(edges + nbins + 1);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // staging area behind the counters, 16-byte aligned
+  const size_t head = (sizeof(double) * (static_cast<size_t>(n_combos) * nbins + nbins + 1) +
+                       sizeof(uint32_t) * n_combos * kCountCopies + 15) / 16 * 16;
+  float4 *my_vec = reinterpret_cast<float4 *>(lds_raw + head) + static_cast<size_t>(wave) * stage;
+  int32_t *my_species =
+      reinterpret_cast<int32_t *>(reinterpret_cast<float4 *>(lds_raw + head) +
+                                  static_cast<size_t>(kThreads / 64) * stage) +
+      static_cast<size_t>(wave) * stage;
   for (int b = threadIdx.x; b < n_combos * nbins; b += kThreads) hist[b] = 0.0;
   for (int b = threadIdx.x; b <= nbins; b += kThreads) edges[b] = g_edges[b];
   for (int b = threadIdx.x; b < n_combos * kCountCopies; b += kThreads) count[b] = 0u;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
   const int64_t f = blockIdx.y;
   const int64_t i_begin = static_cast<int64_t>(blockIdx.x) * atoms_per_block;
   const int64_t i_end = min(n_atoms, i_begin + atoms_per_block);
@@ -304,20 +325,55 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
           : -1;
   for (int64_t i = i_begin + wave; i < i_end; i += kThreads / 64) {
     const int n = min(counts[f * n_atoms + i], capacity);
+    if (n < 2) continue;
     const int64_t base = (f * n_atoms + i) * capacity;
     const int si = atom_species[i];
-    const int n_pairs = n * n;
+    if (kStaged) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the previous atom's list is no longer read
+      for (int a = lane; a < n; a += 64) {
+        my_vec[a] = nbr_vec[base + a];
+        my_species[a] = atom_species[nbr_index[base + a]];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // unordered pairs: n * full_steps of them with every a, then (n even) n/2 more
+    const int full_steps = (n - 1) / 2;
+    const int n_pairs = n * full_steps + ((n & 1) ? 0 : n / 2);
+    const uint32_t magic = 0xFFFFFFFFu / static_cast<uint32_t>(n) + 1u;
     for (int pidx = lane; pidx < n_pairs; pidx += 64) {
-      const int a = pidx / n;
-      const int b = pidx - a * n;
-      if (a == b) continue;
-      const int j = nbr_index[base + a];
-      const int k = nbr_index[base + b];
-      const int combo = combo_of[(si * n_species + atom_species[j]) * n_species +
-                                 atom_species[k]];
+      int a, step;
+      if (pidx < n * full_steps) {
+        // the multiply-high quotient is exact while pidx * n < 2^32
+        step = (n < 1024) ? static_cast<int>(__umulhi(static_cast<uint32_t>(pidx), magic))
+                          : pidx / n;
+        a = pidx - step * n;
+        step += 1;
+      } else {
+        a = pidx - n * full_steps;
+        step = n / 2;
+      }
+      int b = a + step;
+      if (b >= n) b -= n;
+      float4 va, vb;
+      int sj, sk;
+      if (kStaged) {
+        va = my_vec[a];
+        vb = my_vec[b];
+        sj = my_species[a];
+        sk = my_species[b];
+      } else {
+        va = nbr_vec[base + a];
+        vb = nbr_vec[base + b];
+        sj = atom_species[nbr_index[base + a]];
+        sk = atom_species[nbr_index[base + b]];
+      }
+      // (i, j, k) in non-decreasing species order, for either order of the pair
+      const int lo = min(sj, sk), hi = max(sj, sk);
+      const int combo = combo_of[(si * n_species + lo) * n_species + hi];
       if (combo < 0) continue;
-      const float4 va = nbr_vec[base + a];
-      const float4 vb = nbr_vec[base + b];
+      const uint32_t times = (sj == sk) ? 2u : 1u;
       float dot = (va.x * vb.x + va.y * vb.y) + va.z * vb.z;
       dot = fminf(fmaxf(dot, -1.0f), 1.0f);
       const float angle = acosf(dot);
@@ -328,8 +384,8 @@ __global__ __launch_bounds__(kThreads) void adf_triplet_kernel(
       bin = max(0, min(bin, nbins - 1));
       while (bin > 0 && v < edges[bin]) --bin;
       while (bin < nbins - 1 && v >= edges[bin + 1]) ++bin;
-      atomicAdd(&hist[combo * nbins + bin], static_cast<double>(weight));
-      atomicAdd(&count[combo * kCountCopies + (lane & (kCountCopies - 1))], 1u);
+      atomicAdd(&hist[combo * nbins + bin], static_cast<double>(weight) * times);
+      atomicAdd(&count[combo * kCountCopies + (lane & (kCountCopies - 1))], times);
     }
   }
   __syncthreads();
@@ -459,9 +515,6 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
     MDX_HIP(hipMemcpyAsync(d_frames.ptr, frames, sizeof(int64_t) * n_frames,
                            hipMemcpyHostToDevice, stream));
   }
-  MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(adf_triplet_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds)));
 
   // Neighbour lists are written in one pass into slots sized from the mean density
   // (twice the expected neighbourhood plus a margin); a frame block whose largest
@@ -594,12 +647,31 @@ int mdx_adf_accumulate(const void *const *species_pos, int dtype, int location, 
     const int atoms_per_block = 64;
     const dim3 tgrid(static_cast<unsigned>(ceil_div(n_atoms, atoms_per_block)),
                      static_cast<unsigned>(nf));
-    hipLaunchKernelGGL(adf_triplet_kernel, tgrid, dim3(kThreads), lds, stream,
-                       d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>(),
-                       d_species.as<int32_t>(), d_combo.as<int32_t>(), n_species, n_combos,
-                       n_atoms, capacity, atoms_per_block, nbins, d_edges.as<double>(),
-                       norm_power, d_hist.as<double>(),
-                       d_triples.as<unsigned long long>());
+    // staging area of the neighbour lists: one list per wave if LDS has the room
+    const size_t lds_head = (lds + 15) / 16 * 16;
+    const size_t lds_staged = lds_head + static_cast<size_t>(kThreads / 64) * capacity * 20;
+    const bool staged = lds_staged <= 96 * 1024;
+    const size_t lds_launch = staged ? lds_staged : lds_head;
+    if (staged) {
+      MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(adf_triplet_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds_launch)));
+      hipLaunchKernelGGL(adf_triplet_kernel<true>, tgrid, dim3(kThreads), lds_launch, stream,
+                         d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>(),
+                         d_species.as<int32_t>(), d_combo.as<int32_t>(), n_species, n_combos,
+                         n_atoms, capacity, capacity, atoms_per_block, nbins,
+                         d_edges.as<double>(), norm_power, d_hist.as<double>(),
+                         d_triples.as<unsigned long long>());
+    } else {
+      MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(adf_triplet_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds_launch)));
+      hipLaunchKernelGGL(adf_triplet_kernel<false>, tgrid, dim3(kThreads), lds_launch, stream,
+                         d_counts.as<int32_t>(), d_index.as<int32_t>(), d_vec.as<float4>(),
+                         d_species.as<int32_t>(), d_combo.as<int32_t>(), n_species, n_combos,
+                         n_atoms, capacity, 0, atoms_per_block, nbins, d_edges.as<double>(),
+                         norm_power, d_hist.as<double>(), d_triples.as<unsigned long long>());
+    }
     MDX_HIP(hipGetLastError());
   }
   std::vector<double> h_hist(static_cast<size_t>(n_combos) * nbins);

@@ -32,6 +32,7 @@ def _density(weights, edges):
     ([33], 2, [6.0, 7.0, 8.0], 2.5, 37, 0),
     ([10, 1, 14], 2, [7.5, 7.5, 7.5], 3.7, 64, 2),
     ([70, 60], 1, [9.0, 9.0, 9.0], 4.4, 500, 4),
+    ([12, 10, 14], 2, [7.5, 7.5, 7.5], 3.7, 1150, 2),  # histograms leave no LDS for the lists
 ])
 def test_adf_matches_oracle(gpu, sizes, n_frames, box, cutoff, nbins, power):
     rng = np.random.default_rng(51)
