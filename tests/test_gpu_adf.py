@@ -104,6 +104,21 @@ def test_adf_cell_list_search(gpu, monkeypatch, sizes, box, cutoff, spread):
         np.testing.assert_allclose(hist_c[c].sum(), ref_weight, rtol=1e-6)
 
 
+def test_adf_cell_list_is_the_default_for_larger_systems(gpu, monkeypatch):
+    """2600 atoms: the default search (cells) and the all-pairs search give the same lists."""
+    rng = np.random.default_rng(55)
+    box, cutoff = [31.0, 29.0, 33.0], 3.0
+    pos = [(rng.random((n, 2, 3)) * np.array(box)).astype(np.float32) for n in (1500, 1100)]
+    edges = _edges(90)
+    monkeypatch.delenv("MDX_ADF_CELL_MIN_ATOMS", raising=False)
+    hist_c, triples_c = gpu.adf_accumulate(pos, box, cutoff, edges, norm_power=4)
+    monkeypatch.setenv("MDX_ADF_CELL_MIN_ATOMS", "1000000")
+    hist_a, triples_a = gpu.adf_accumulate(pos, box, cutoff, edges, norm_power=4)
+    assert triples_c.sum() > 0
+    np.testing.assert_array_equal(triples_c, triples_a)
+    np.testing.assert_allclose(hist_c, hist_a, rtol=1e-9, atol=1e-9 * hist_a.max())
+
+
 def test_adf_frame_selection_device_input_and_float64(gpu):
     rng = np.random.default_rng(52)
     sizes, box, cutoff, nbins = [25, 30], [8.0, 8.0, 8.0], 3.2, 80
