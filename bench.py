@@ -82,6 +82,12 @@ def recorded_traffic(kernel_key: str):
 
 def main() -> None:
     args = parse_args()
+    # Native libraries write banners to file descriptor 1 (RCCL prints its version block
+    # when the first communicator is created).  Everything except the result line goes to
+    # stderr: descriptor 1 points there until the JSON line is written to the saved copy.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,7 +268,9 @@ def main() -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        with os.fdopen(result_fd, "w") as result_stream:
+            result_stream.write(json.dumps(result) + "\n")
 
 
 def host_input_measurement(engine, fps: int) -> dict:
