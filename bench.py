@@ -80,6 +80,21 @@ def recorded_traffic(kernel_key: str):
         return None
 
 
+def recorded_counter(kernel_key: str, counter: str):
+    """Mean of a hardware counter per launch of the longest-running grid of a kernel, from
+    the same committed summary as ``recorded_traffic``; None when not recorded."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)
+        entries = [v for k, v in table.items() if k.startswith(kernel_key) and counter in v]
+        if not entries:
+            return None
+        return max(entries, key=lambda v: v["mean_duration_us_under_pmc"])[counter]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main() -> None:
     args = parse_args()
     # Native libraries write banners to file descriptor 1 (RCCL prints its version block
@@ -227,6 +242,16 @@ def main() -> None:
         "pack_kernel_ms_total": pack_ms,
         "tile_kernel_ms_total": tile_ms,
     }
+    # measured side of the same statement: wave-level VALU instructions per launch from
+    # the SQ counter pass, 4 cycles each on one of 1024 SIMDs (v_sqrt_f32 takes 8, so
+    # the true busy fraction is higher), against the launch time measured here
+    valu_insts = recorded_counter("rdf_tile_kernel<false>", "SQ_INSTS_VALU") \
+        if (fps == 1024 and not args.literal_kernel) else None
+    if valu_insts:
+        valu["valu_insts_per_launch_pmc"] = valu_insts
+        valu["valu_insts_per_pair_slot"] = valu_insts * 64 / (pairs_per_frame * frames_per_launch)
+        valu["simd_issue_busy_frac_at_2p4GHz"] = (valu_insts * 4.0 / 1024
+                                                  / (tile_avg_ms * 1e-3 * 2.4e9))
 
     result = {
         "metric": "frames/sec (RDF + GK-ACF) on 10k-atom synthetic trajectory; %HBM-roofline",
