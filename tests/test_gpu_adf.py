@@ -119,6 +119,22 @@ def test_adf_cell_list_is_the_default_for_larger_systems(gpu, monkeypatch):
     np.testing.assert_allclose(hist_c, hist_a, rtol=1e-9, atol=1e-9 * hist_a.max())
 
 
+@pytest.mark.parametrize("n_side,cells", [(4, False), (7, True)])
+def test_adf_known_answer_on_a_cubic_lattice(gpu, monkeypatch, n_side, cells):
+    """6 neighbours per atom, 24 right angles and 6 straight ones per atom and frame: the
+    histogram is known exactly (weights are powers of two), for both pair searches."""
+    from test_oracle_reference_pins import (cubic_lattice_adf_expectation,
+                                            cubic_lattice_positions)
+    monkeypatch.setenv("MDX_ADF_CELL_MIN_ATOMS", "1" if cells else "1000000")
+    nbins, power, n_frames = 63, 2, 2
+    pos = cubic_lattice_positions(n_side, n_frames)
+    box = [n_side * 2.0] * 3
+    edges, triples, expected = cubic_lattice_adf_expectation(n_side, nbins, power)
+    hist, counts = gpu.adf_accumulate([pos], box, 2.4, edges, norm_power=power)
+    assert int(counts[0]) == n_frames * triples
+    np.testing.assert_array_equal(hist[0], n_frames * expected)
+
+
 def test_adf_frame_selection_device_input_and_float64(gpu):
     rng = np.random.default_rng(52)
     sizes, box, cutoff, nbins = [25, 30], [8.0, 8.0, 8.0], 3.2, 80

@@ -323,3 +323,38 @@ def test_rdf_oracles_count_the_shells_of_a_cubic_lattice():
     strict = orc_rdf.rdf_histograms([pos], ["Ar"], box, cutoff, nbins, rdf_minibatch=64)
     full = lattice_histogram(nbins, cutoff).astype(np.int64)
     np.testing.assert_array_equal(strict["Ar_Ar"].astype(np.int64), full - full // 256)
+
+
+def cubic_lattice_adf_expectation(n_side, nbins, power, spacing=2.0):
+    """Known answer for a periodic simple cubic lattice with the cutoff between the first and
+    second shell: every atom has 6 neighbours, 30 ordered neighbour pairs, 24 of them at a
+    right angle and 6 opposite; all vectors, unit vectors and cosines are exact in float32."""
+    n_atoms = n_side ** 3
+    edges = np.histogram_bin_edges(np.zeros(1, dtype=np.float32), bins=nbins, range=(0.0, 3.15))
+    weight = 1.0 / (spacing * spacing) ** power
+    expected = np.zeros(nbins)
+    for angle, count in ((np.float32(np.arccos(np.float32(0.0))), 24),
+                         (np.float32(np.arccos(np.float32(-1.0))), 6)):
+        expected[np.searchsorted(edges, np.float64(angle), side="right") - 1] += \
+            count * n_atoms * weight
+    return edges, 30 * n_atoms, expected
+
+
+def cubic_lattice_positions(n_side, n_frames, spacing=2.0):
+    grid = np.arange(n_side, dtype=np.float32) * np.float32(spacing)
+    pos = np.stack(np.meshgrid(grid, grid, grid, indexing="ij"), axis=-1).reshape(-1, 3)
+    return np.repeat(pos[:, None, :], n_frames, axis=1).astype(np.float32)
+
+
+def test_adf_oracle_counts_the_angles_of_a_cubic_lattice():
+    from oracle import adf as ora
+
+    n_side, nbins, power = 4, 63, 2
+    pos = cubic_lattice_positions(n_side, 1)
+    box = [n_side * 2.0] * 3
+    edges, triples, expected = cubic_lattice_adf_expectation(n_side, nbins, power)
+    hist, count, weight_sum = ora.adf_batch([pos], box, 2.4, nbins, power)[(0, 0, 0)]
+    assert count == triples
+    np.testing.assert_allclose(weight_sum, expected.sum(), rtol=1e-6)
+    density = expected / np.diff(edges) / expected.sum()
+    np.testing.assert_allclose(hist, density.astype(np.float32), rtol=1e-5)
