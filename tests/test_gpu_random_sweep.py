@@ -22,7 +22,7 @@ def _close(got, ref, rtol=1e-6):
     np.testing.assert_allclose(got, ref, rtol=0.0, atol=rtol * scale)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_rdf_random_configurations(gpu, seed):
     rng = np.random.default_rng(1000 + seed)
     n_species = int(rng.integers(1, 4))
@@ -57,7 +57,7 @@ def test_rdf_random_configurations(gpu, seed):
         np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_acf_random_window_layouts(gpu, seed):
     rng = np.random.default_rng(2000 + seed)
     n_series = int(rng.choice([1, 1, 1, 2, 5, 9, 40]))
@@ -88,7 +88,7 @@ def test_acf_random_window_layouts(gpu, seed):
     _close(mom.std(), np.std(sig, axis=0))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(30))
 def test_msd_random_window_layouts(gpu, seed):
     rng = np.random.default_rng(3000 + seed)
     n_series = int(rng.choice([1, 3, 8, 9, 33, 70]))
@@ -111,7 +111,7 @@ def test_msd_random_window_layouts(gpu, seed):
     _close(got, ref)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(20))
 def test_atom_sum_and_transformations_random_shapes(gpu, seed):
     from oracle import transformations as ort
 
