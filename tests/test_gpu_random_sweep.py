@@ -138,3 +138,33 @@ def test_atom_sum_and_transformations_random_shapes(gpu, seed):
         vel = gpu.map_coordinates(gpu.MAP_VELOCITY, got, [0.004, 0.0, 0.0])
         np.testing.assert_array_equal(
             vel, np.asarray(ort.velocity_from_positions(np.asarray(ref), 0.002, 2)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_adf_random_configurations(gpu, monkeypatch, seed):
+    import itertools
+
+    from oracle import adf as ora
+
+    rng = np.random.default_rng(5000 + seed)
+    n_species = int(rng.integers(1, 4))
+    sizes = [int(rng.choice([1, 3, 20, 45, 80])) for _ in range(n_species)]
+    box = [float(b) for b in rng.uniform(7.0, 14.0, 3)]
+    cutoff = float(rng.uniform(1.5, 0.45 * min(box)))
+    nbins = int(rng.choice([10, 64, 500]))
+    power = int(rng.choice([0, 2, 4]))
+    n_frames = int(rng.integers(1, 4))
+    outside = rng.random() < 0.3  # coordinates several boxes away
+    pos = [((rng.random((n, n_frames, 3)) - (2.0 if outside else 0.0)) * np.asarray(box)
+            * (3.0 if outside else 1.0)).astype(np.float32) for n in sizes]
+    # either pair search (the cell list needs three cells per axis, else it is not used)
+    monkeypatch.setenv("MDX_ADF_CELL_MIN_ATOMS", "1" if rng.random() < 0.5 else "1000000")
+    edges = np.histogram_bin_edges(np.zeros(1, dtype=np.float32), bins=nbins, range=(0.0, 3.15))
+    hist, triples = gpu.adf_accumulate(pos, box, cutoff, edges, norm_power=power)
+    ref = ora.adf_batch(pos, box, cutoff, nbins, power)
+    combos = list(itertools.combinations_with_replacement(range(n_species), 3))
+    for c, key in enumerate(combos):
+        ref_hist, ref_count, ref_weight = ref[key]
+        assert int(triples[c]) == ref_count, key
+        if ref_count:
+            np.testing.assert_allclose(hist[c].sum(), ref_weight, rtol=1e-6)
