@@ -11,7 +11,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "mdx.h"
@@ -102,6 +104,10 @@ struct DeviceBuffer {
 // the device, else a staged copy held by `staging` (async copy on `stream`).
 int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
               hipStream_t stream, const void **dptr);
+
+// Host-to-device copy in stream order; large ranges are pipelined through page-locked
+// memory.  The host range has been read when the call returns.
+int upload(void *dst, const void *src, size_t bytes, hipStream_t stream);
 
 // Brackets the kernel launches issued during its lifetime with HIP events when
 // profiling is enabled (mdx_profile_enable); free otherwise.

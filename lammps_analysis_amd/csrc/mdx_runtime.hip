@@ -134,6 +134,104 @@ int get_copy_stream(hipStream_t *stream) {
   return MDX_OK;
 }
 
+// ---- large host-to-device copies
+//
+// hipMemcpy from pageable memory moves about 30 GB/s on this platform, from page-locked
+// memory 57 GB/s.  Large uploads therefore go through two page-locked twins of 64 MiB:
+// four host threads fill one twin (58 GB/s) while the previous one is on the wire.  The
+// twins are kept per device for the life of the process (released with the cached device
+// memory); one upload at a time uses them.
+namespace {
+constexpr size_t kUploadChunk = size_t(64) << 20;
+constexpr size_t kUploadThreshold = size_t(96) << 20;
+constexpr int kUploadThreads = 4;
+struct UploadTwins {
+  void *pinned[2] = {nullptr, nullptr};
+  hipEvent_t sent[2] = {nullptr, nullptr};
+};
+std::mutex g_upload_mutex;
+UploadTwins g_upload[kMaxDevices];
+
+void release_upload_twins_locked(int dev) {
+  UploadTwins &tw = g_upload[dev];
+  for (int b = 0; b < 2; ++b) {
+    if (tw.sent[b] != nullptr) (void)hipEventDestroy(tw.sent[b]);
+    if (tw.pinned[b] != nullptr) (void)hipHostFree(tw.pinned[b]);
+    tw.sent[b] = nullptr;
+    tw.pinned[b] = nullptr;
+  }
+}
+
+bool prepare_upload_twins_locked(int dev) {
+  UploadTwins &tw = g_upload[dev];
+  if (tw.pinned[1] != nullptr) return true;
+  for (int b = 0; b < 2; ++b) {
+    if (hipHostMalloc(&tw.pinned[b], kUploadChunk, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&tw.sent[b], hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      release_upload_twins_locked(dev);
+      return false;
+    }
+  }
+  return true;
+}
+
+void parallel_copy(char *dst, const char *src, size_t bytes) {
+  const size_t part = (bytes / kUploadThreads + 4095) / 4096 * 4096;
+  std::thread workers[kUploadThreads - 1];
+  int started = 0;
+  for (int t = 1; t < kUploadThreads; ++t) {
+    const size_t begin = static_cast<size_t>(t) * part;
+    if (begin >= bytes) break;
+    const size_t n = std::min(part, bytes - begin);
+    workers[started++] = std::thread([=] { memcpy(dst + begin, src + begin, n); });
+  }
+  memcpy(dst, src, std::min(part, bytes));
+  for (int t = 0; t < started; ++t) workers[t].join();
+}
+}  // namespace
+
+// Copies `bytes` from host to device memory in stream order.  The host range has been
+// read when the call returns; the device side completes on `stream`.
+int upload(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return MDX_OK;
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  if (bytes >= kUploadThreshold && dev >= 0 && dev < kMaxDevices) {
+    std::lock_guard<std::mutex> lock(g_upload_mutex);
+    if (prepare_upload_twins_locked(dev)) {
+      UploadTwins &tw = g_upload[dev];
+      const char *from = static_cast<const char *>(src);
+      char *to = static_cast<char *>(dst);
+      int index = 0;
+      for (size_t off = 0; off < bytes; off += kUploadChunk, ++index) {
+        const int b = index & 1;
+        const size_t n = std::min(kUploadChunk, bytes - off);
+        if (index >= 2) MDX_HIP(hipEventSynchronize(tw.sent[b]));  // the twin has left
+        parallel_copy(static_cast<char *>(tw.pinned[b]), from + off, n);
+        MDX_HIP(hipMemcpyAsync(to + off, tw.pinned[b], n, hipMemcpyHostToDevice, stream));
+        MDX_HIP(hipEventRecord(tw.sent[b], stream));
+      }
+      // the twins belong to the next upload once both have left
+      MDX_HIP(hipEventSynchronize(tw.sent[0]));
+      if (index >= 2) MDX_HIP(hipEventSynchronize(tw.sent[1]));
+      return MDX_OK;
+    }
+  }
+  MDX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+  return MDX_OK;
+}
+
+void release_upload_twins() {
+  std::lock_guard<std::mutex> lock(g_upload_mutex);
+  int current = 0;
+  if (hipGetDevice(&current) != hipSuccess) return;
+  for (int dev = 0; dev < kMaxDevices; ++dev) {
+    if (g_upload[dev].pinned[0] == nullptr && g_upload[dev].pinned[1] == nullptr) continue;
+    release_upload_twins_locked(dev);
+  }
+}
+
 int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging,
               hipStream_t stream, const void **dptr) {
   if (src == nullptr) return fail(MDX_ERR_INVALID_ARGUMENT, "null data pointer");
@@ -144,7 +242,7 @@ int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging
   if (location != MDX_HOST)
     return fail(MDX_ERR_INVALID_ARGUMENT, "location must be MDX_HOST or MDX_DEVICE");
   MDX_TRY(staging.alloc(bytes));
-  MDX_HIP(hipMemcpyAsync(staging.ptr, src, bytes, hipMemcpyHostToDevice, stream));
+  MDX_TRY(upload(staging.ptr, src, bytes, stream));
   *dptr = staging.ptr;
   return MDX_OK;
 }
@@ -281,6 +379,7 @@ int mdx_free(void *dptr) {
 
 int mdx_release_cached_memory(void) {
   pool_trim();
+  release_upload_twins();
   return MDX_OK;
 }
 
@@ -288,7 +387,7 @@ int mdx_memcpy_h2d(void *dptr, const void *host, size_t bytes) {
   MDX_REQUIRE(dptr != nullptr && host != nullptr, "null pointer");
   hipStream_t s;
   MDX_TRY(get_stream(&s));
-  MDX_HIP(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, s));
+  MDX_TRY(upload(dptr, host, bytes, s));
   MDX_HIP(hipStreamSynchronize(s));
   return MDX_OK;
 }
