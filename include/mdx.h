@@ -68,7 +68,9 @@ int mdx_memcpy_h2d(void *dptr, const void *host, size_t bytes);
 int mdx_memcpy_d2h(void *host, const void *dptr, size_t bytes);
 int mdx_memset(void *dptr, int byte_value, size_t bytes);
 /* The library keeps the scratch blocks its calls free in a per-device cache (at
- * most 8 GiB) instead of returning them to the driver; this releases them. */
+ * most 8 GiB) instead of returning them to the driver, and two 64 MiB page-locked host
+ * buffers per device once a host array of 96 MiB or more has been uploaded; this
+ * releases both. */
 int mdx_release_cached_memory(void);
 
 /* HIP events recorded on the library stream (the stream every kernel of this
