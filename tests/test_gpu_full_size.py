@@ -86,3 +86,20 @@ def test_acf_million_frame_series_against_weighted_sum(gpu, data_range):
         count = np.clip(hi - lo + 1, 0, None)
         expected = float(np.dot(prod, count)) / (D - m)
         assert abs(acf[m] - expected) <= 1e-9 * abs(acf[0]), (m, acf[m], expected)
+
+
+def test_large_host_arrays_take_the_page_locked_upload_path(gpu):
+    """Host arrays of 96 MiB and more are sent in 64 MiB pieces through page-locked
+    buffers filled by several threads: every byte must arrive, also when the size is not a
+    multiple of anything, and a kernel fed from such an array must see the same data."""
+    rng = np.random.default_rng(77)
+    odd = rng.integers(0, 2 ** 31, size=(200 * 1024 * 1024 + 12_345) // 4, dtype=np.int32) \
+        .view(np.float32)[:-1]
+    dev = gpu.DeviceArray.from_numpy(odd)
+    np.testing.assert_array_equal(dev.to_numpy().view(np.int32), odd.view(np.int32))
+    dev.free()
+    x = rng.random((300, 30_000, 3), dtype=np.float32)  # 108 MB
+    got = gpu.weighted_atom_sum(x, scalar_weight=1.0)
+    small = gpu.weighted_atom_sum(x[:, :100].copy(), scalar_weight=1.0)
+    np.testing.assert_array_equal(got[:100], small)
+    np.testing.assert_allclose(got, x.astype(np.float64).sum(axis=0), rtol=1e-12)
