@@ -29,6 +29,8 @@ log = logging.getLogger(__name__)
 # Device-side batching: frames are sent to the GPU in blocks of about this many
 # bytes of float32 positions.  Integer counts do not depend on the blocking.
 _DEVICE_BATCH_BYTES = 1 << 30
+# stored arrays up to this size may go to the device whole (a dense, strided frame sample)
+_DEVICE_RESIDENT_BYTES = 64 << 30
 
 
 @dataclass
@@ -229,6 +231,43 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
 
     # --------------------------------------------------------------------- run
 
+    def _accumulate_from_the_store(self, rdf_engine, rank: int, size: int) -> bool:
+        """Hand the stored arrays themselves to the engine when that is cheaper than
+        gathering the sampled frames on the host first.
+
+        Whole species and a dense sample only: long runs of consecutive frames are
+        streamed from the memory maps block by block (no host copy at all); a strided but
+        dense sample is sent with its frame list, the whole array going to the device.
+        Histogram counts do not depend on how frames are grouped, so the result equals the
+        batch loop's.  Returns False when the batch loop should run instead."""
+        if self.args.molecules or not (isinstance(self.args.atom_selection, slice)
+                                       and self.args.atom_selection == slice(None)):
+            return False
+        sample = np.asarray(self.sample_configurations, dtype=np.int64)
+        if sample.size == 0 or np.any(np.diff(sample) < 0):
+            return False
+        paths = [join_path(item, self.loaded_property.name) for item in self.args.species]
+        data = self.database.load_data(paths, select_slice=np.s_[:])
+        views = [data[p] for p in paths]
+        if any(v.ndim != 3 or v.dtype != np.float32 or not v.flags.c_contiguous for v in views):
+            return False
+        n_stored = views[0].shape[1]
+        if sample[-1] >= n_stored:
+            return False
+        # maximal runs of consecutive frame indices
+        breaks = np.flatnonzero(np.diff(sample) != 1) + 1
+        runs = np.split(sample, breaks)
+        if len(runs) <= 16 and all(len(r) >= 128 for r in runs):
+            for run in runs:
+                rdf_engine.accumulate(views, frame_range=(int(run[0]), int(run[-1]) + 1),
+                                      shard_rank=rank, shard_count=size)
+            return True
+        total_bytes = sum(v.nbytes for v in views)
+        if 4 * sample.size >= n_stored and total_bytes <= _DEVICE_RESIDENT_BYTES:
+            rdf_engine.accumulate(views, frames=sample, shard_rank=rank, shard_count=size)
+            return True
+        return False
+
     def run_calculator(self):
         self.check_input()
         dict_keys, split_arr, _ = self.prepare_computation()
@@ -242,13 +281,14 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
         rdf_engine = engine.RdfEngine(particles, box, np.float32(self.args.cutoff),
                                       self.args.number_of_bins,
                                       strict_reference_masks=self.strict_reference_masks)
-        batch_ds = self.get_batch_dataset(subject_list=self.args.species,
-                                          loop_array=split_arr, correct=True)
-        for batch in batch_ds:
-            positions = [np.ascontiguousarray(batch[key], dtype=np.float32)
-                         for key in dict_keys]
-            # every rank sees the same frames and evaluates its share of pair tiles
-            rdf_engine.accumulate(positions, shard_rank=rank, shard_count=size)
+        if not self._accumulate_from_the_store(rdf_engine, rank, size):
+            batch_ds = self.get_batch_dataset(subject_list=self.args.species,
+                                              loop_array=split_arr, correct=True)
+            for batch in batch_ds:
+                positions = [np.ascontiguousarray(batch[key], dtype=np.float32)
+                             for key in dict_keys]
+                # every rank sees the same frames and evaluates its share of pair tiles
+                rdf_engine.accumulate(positions, shard_rank=rank, shard_count=size)
         histograms = parallel.all_reduce_sum(rdf_engine.read())
         rdf_engine.close()
         self.histograms = {key: histograms[i] for i, key in enumerate(self.key_list)}

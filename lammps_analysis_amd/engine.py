@@ -199,11 +199,14 @@ class RdfEngine:
         return int(n.value)
 
     def accumulate(self, species_positions: Sequence[ArrayLike], frames=None,
-                   shard_rank: int = 0, shard_count: int = 1) -> None:
+                   shard_rank: int = 0, shard_count: int = 1, frame_range=None) -> None:
         """Add the histogram of the selected frames.
 
         ``species_positions[s]`` is ``[n_s, F, 3]`` (all on the host or all on the
-        device, one dtype); ``frames`` indexes axis 1 (default: every frame).
+        device, one dtype); ``frames`` indexes axis 1 (default: every frame);
+        ``frame_range = (begin, end)`` selects consecutive frames instead — host arrays
+        (memory maps included) are then streamed block by block, without a copy of the
+        range and without the whole array going to the device.
         """
         if len(species_positions) != self.n_species:
             raise ValueError("one position array per species is required")
@@ -222,7 +225,18 @@ class RdfEngine:
             raise ValueError("all species arrays must hold the same number of frames")
         frame_stride = strides.pop()
         ptrs = (ctypes.c_void_p * self.n_species)(*[i[0] for i in infos])
-        if frames is None:
+        if frame_range is not None:
+            if frames is not None:
+                raise ValueError("give either frames or frame_range")
+            begin, end = int(frame_range[0]), int(frame_range[1])
+            if not 0 <= begin <= end <= frame_stride:
+                raise ValueError(f"frame_range {frame_range} outside [0, {frame_stride}]")
+            itemsize = 4 if next(iter(dtypes)) == _dtype_code(np.float32) else 8
+            ptrs = (ctypes.c_void_p * self.n_species)(
+                *[(i[0] + begin * 3 * itemsize) if i[0] else i[0] for i in infos])
+            frames_ptr = None
+            n_frames = end - begin
+        elif frames is None:
             frames_ptr = None
             n_frames = frame_stride
         else:

@@ -1,0 +1,68 @@
+"""End to end through the product API: a 10k-atom trajectory in the on-disk store
+(memory-mapped .npy), calculators run as a user would run them."""
+import os, sys, tempfile, time
+import numpy as np
+import lammps_analysis_amd as mds
+from lammps_analysis_amd.database.mdsuite_properties import mdsuite_properties
+from lammps_analysis_amd.database.simulation_database import (SpeciesInfo, TrajectoryChunkData,
+                                                              TrajectoryMetadata)
+
+n_atoms, n_frames = 5000, int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+tmp = tempfile.mkdtemp(dir=os.environ.get("TMPDIR", "/tmp"))
+os.chdir(tmp)
+rng = np.random.default_rng(0)
+project = mds.Project()
+exp = project.add_experiment("melt", timestep=0.002, temperature=1400.0, units="metal")
+props = [mdsuite_properties.positions, mdsuite_properties.velocities,
+         mdsuite_properties.unwrapped_positions]
+species = [SpeciesInfo(name=n, n_particles=n_atoms, properties=props, charge=q)
+           for n, q in (("Na", 1.0), ("Cl", -1.0))]
+meta = TrajectoryMetadata(species_list=species, n_configurations=n_frames, sample_rate=1,
+                          box_l=[65.0, 65.0, 65.0])
+t0 = time.perf_counter()
+chunk_frames = 500
+from lammps_analysis_amd.file_io.file_read import FileProcessor
+
+
+class Synthetic(FileProcessor):
+    def __str__(self):
+        return "synthetic"
+
+    def _get_metadata(self):
+        return meta
+
+    def get_configurations_generator(self):
+        for f0 in range(0, n_frames, chunk_frames):
+            nf = min(chunk_frames, n_frames - f0)
+            chunk = TrajectoryChunkData(species_list=species, chunk_size=nf)
+            for sp in species:
+                pos = rng.random((nf, n_atoms, 3), dtype=np.float32) * 65.0
+                chunk.add_data(pos, 0, sp.name, "Positions")
+                chunk.add_data(pos, 0, sp.name, "Unwrapped_Positions")
+                chunk.add_data(rng.standard_normal((nf, n_atoms, 3), dtype=np.float32), 0,
+                               sp.name, "Velocities")
+            yield chunk
+
+
+exp.add_data(Synthetic())
+print(f"ingest {n_frames} frames x {2*n_atoms} atoms: {time.perf_counter()-t0:.1f} s", flush=True)
+
+def timed(label, fn):
+    t0 = time.perf_counter(); out = fn(); dt = time.perf_counter() - t0
+    print(f"{label}: {dt*1e3:.0f} ms", flush=True)
+    return out
+timed("RadialDistributionFunction(500 configurations)",
+      lambda: exp.run.RadialDistributionFunction(number_of_configurations=500, plot=False))
+timed("RadialDistributionFunction(all configurations)",
+      lambda: exp.run.RadialDistributionFunction(number_of_configurations=-1, plot=False))
+timed("GreenKuboIonicConductivity (incl. IonicCurrent transformation)",
+      lambda: exp.run.GreenKuboIonicConductivity(data_range=500, plot=False))
+timed("GreenKuboIonicConductivity again (series in the store)",
+      lambda: exp.run.GreenKuboIonicConductivity(data_range=500, plot=False, correlation_time=2))
+timed("GreenKuboDiffusionCoefficients",
+      lambda: exp.run.GreenKuboDiffusionCoefficients(data_range=500, plot=False))
+timed("EinsteinDiffusionCoefficients",
+      lambda: exp.run.EinsteinDiffusionCoefficients(data_range=100, plot=False))
+timed("AngularDistributionFunction(50 configurations, cutoff 6)",
+      lambda: exp.run.AngularDistributionFunction(number_of_configurations=50, cutoff=6.0,
+                                                  plot=False))
