@@ -178,6 +178,29 @@ def test_rdf_calculator_matches_oracle_and_caches(gpu, tmp_path):
                                       np.asarray(ref_full[key]["y"])[1:])
 
 
+def test_rdf_calculator_streams_long_frame_runs_from_the_store(gpu, tmp_path):
+    """A dense sample over a few hundred frames: runs of consecutive frames are streamed
+    from the store's memory maps, a strided dense sample goes by frame list, a sparse one
+    through the batch loop; all three agree with the oracle count for count."""
+    rng = np.random.default_rng(8)
+    box, n_step = 11.0, 300
+    pos_na, pos_cl, _, _ = _nacl(rng, 37, 45, n_step, box)
+    project = mds.Project(name="rdf_stream", storage_path=tmp_path)
+    exp = project.add_experiment("NaCl", timestep=0.002, temperature=1400.0, units="metal")
+    _add(exp, {"Na": {mdsuite_properties.positions: pos_na},
+               "Cl": {mdsuite_properties.positions: pos_cl}}, n_step, box_l=[box] * 3)
+    stored = [np.swapaxes(pos_na, 0, 1).astype(np.float32),
+              np.swapaxes(pos_cl, 0, 1).astype(np.float32)]
+    for n_cfg in (-1, 150, 20):   # two runs of ~150 frames / every other frame / sparse
+        got = exp.run.RadialDistributionFunction(number_of_configurations=n_cfg, plot=False)
+        ref, _ = orc_rdf.radial_distribution_function(
+            stored, ["Na", "Cl"], {"Na": 37, "Cl": 45}, [box] * 3, mds.units.METAL.length,
+            number_of_configurations=n_cfg)
+        for key in ref:
+            np.testing.assert_array_equal(np.asarray(got[key]["y"])[1:],
+                                          np.asarray(ref[key]["y"])[1:])
+
+
 def test_green_kubo_ionic_conductivity_chain(gpu, tmp_path):
     """Velocities -> IonicCurrent transformation (GPU reduction, float32 storage) ->
     windowed ACF, against the oracle chain."""
