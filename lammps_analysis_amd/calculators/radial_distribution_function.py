@@ -235,7 +235,7 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
         """Hand the stored arrays themselves to the engine when that is cheaper than
         gathering the sampled frames on the host first.
 
-        Whole species and a dense sample only: long runs of consecutive frames are
+        Whole species and a sample of at least one frame in 32 only: long runs of consecutive frames are
         streamed from the memory maps block by block (no host copy at all); a strided but
         dense sample is sent with its frame list, the whole array going to the device.
         Histogram counts do not depend on how frames are grouped, so the result equals the
@@ -263,7 +263,9 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
                                       shard_rank=rank, shard_count=size)
             return True
         total_bytes = sum(v.nbytes for v in views)
-        if 4 * sample.size >= n_stored and total_bytes <= _DEVICE_RESIDENT_BYTES:
+        # the upload of a whole array (53 GB/s) beats a host-side gather of the sampled frames
+        # (about 1.5 GB/s through a fancy index) down to one frame in 32
+        if 32 * sample.size >= n_stored and total_bytes <= _DEVICE_RESIDENT_BYTES:
             rdf_engine.accumulate(views, frames=sample, shard_rank=rank, shard_count=size)
             return True
         return False
