@@ -40,6 +40,7 @@ N_CL = 5000
 BOX = 65.0
 CUTOFF = np.float32(BOX / 2 - 0.1)
 NBINS = int(CUTOFF / 0.01)
+TRAJECTORY_FRAMES = 100000       # BASELINE.json configs[1]: 10k atoms x 100k frames
 HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak
 F32_VALU_PEAK_TFLOPS = 157.3     # MI355X vector fp32 spec peak (FMA counted as 2)
 
@@ -49,7 +50,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=1024)
+    ap.add_argument("--frames-per-step", type=int, default=0,
+                    help="frames per step; 0 = the configuration's 100 000 frames divided "
+                         "over the timed steps")
     ap.add_argument("--cpu-frames", type=int, default=24,
                     help="frames of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--gk-frames", type=int, default=100000,
@@ -97,58 +100,42 @@ def recorded_counter(kernel_key: str, counter: str):
 
 def main() -> None:
     args = parse_args()
+    env_world = os.environ.get("MDX_WORLD_SIZE") or os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        # started as a plain command: this process becomes the launcher of N ranks (one
+        # per GPU) and never touches a GPU itself; rank 0 prints the result line
+        from lammps_analysis_amd import parallel as launcher
+        raise SystemExit(launcher.launch([os.path.abspath(__file__), *sys.argv[1:]], args.gpus))
     # Native libraries write banners to file descriptor 1 (RCCL prints its version block
     # when the first communicator is created).  Everything except the result line goes to
     # stderr: descriptor 1 points there until the JSON line is written to the saved copy.
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    dist = None
-    torch = None
-    # BENCH_FORCE_DIST=1 initialises the process group even for one rank (rehearsal
-    # of the multi-rank code path on a single GPU)
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        # plumbing only: rendezvous, barrier, max-reduce, one all-reduce.  torch ships
-        # its own HIP runtime; it has to be loaded before libmdx.so so that both use one
-        # runtime (the loader then resolves libmdx's libamdhip64.so.7 to the loaded one).
-        import torch
-        import torch.distributed as dist
-
-    from lammps_analysis_amd import _lib, engine
+    from lammps_analysis_amd import _lib, engine, parallel
 
     _lib.load()
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: no HIP device is visible to libmdx")
-
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        # "nccl" is RCCL over xGMI; BENCH_DIST_BACKEND=gloo lets several ranks share
-        # one GPU to rehearse this path on a single-GPU machine
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        device_index = local_rank % _lib.device_count()
-        torch.cuda.set_device(device_index)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        comm_device = "cuda" if backend == "nccl" else "cpu"
-    else:
-        device_index = local_rank
-    engine.set_device(device_index)
+    # BENCH_FORCE_COMM=1 creates the RCCL communicator even for one rank (rehearsal of
+    # the collective on a single GPU)
+    force = os.environ.get("BENCH_FORCE_COMM") == "1"
+    rank, world = parallel.init(transport="rccl" if (force and env_world is None) else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    local_rank = int(os.environ.get("MDX_LOCAL_RANK") or os.environ.get("LOCAL_RANK") or rank)
+    engine.set_device(local_rank % _lib.device_count())
 
     def barrier_sync():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
         engine.synchronize()
+        parallel.barrier()
 
-    steps, warmup, fps = args.steps, args.warmup, args.frames_per_step
-    n_frames = fps * (steps + warmup)
+    steps, warmup = args.steps, args.warmup
+    fps = args.frames_per_step if args.frames_per_step > 0 else max(1, TRAJECTORY_FRAMES // steps)
+    # the timed steps walk once through the resident trajectory (100 000 frames per rank
+    # with the default step size); warm-up steps re-read its first blocks
+    n_frames = fps * steps
 
     # ---- resident synthetic trajectory, reference layout [atoms][frames][3]
     na = engine.DeviceArray((N_NA, n_frames, 3), np.float32)
@@ -165,13 +152,13 @@ def main() -> None:
         rdf.accumulate(species, frames=np.arange(i * fps, (i + 1) * fps, dtype=np.int64))
 
     for i in range(warmup):
-        step(i)
+        step(i % steps)
     rdf.reset()
     engine.profile_enable(True)
     engine.profile_reset()
     barrier_sync()
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
+    for i in range(steps):
         step(i)
     barrier_sync()
     elapsed = time.perf_counter() - t0
@@ -179,22 +166,21 @@ def main() -> None:
     tile_ms, tile_launches = engine.profile_query("rdf_tile")
     pack_ms, pack_launches = engine.profile_query("rdf_pack")
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(parallel.all_reduce_max([elapsed])[0])  # the slowest rank's time
 
-    hist_local = rdf.read()
+    # the one exchange step of the run: per-rank histograms summed over the ranks
     allreduce_ms = None
-    hist_total = hist_local
-    if dist is not None:
-        h = torch.from_numpy(hist_local.astype(np.int64)).to(comm_device)
-        torch.cuda.synchronize()
+    if world > 1 or parallel.communicator() is not None:
+        barrier_sync()
         ta = time.perf_counter()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM)
-        torch.cuda.synchronize()
+        if parallel.communicator() is not None:
+            rdf.reduce(parallel.communicator())  # in place on the devices, RCCL
+            hist_total = rdf.read()
+        else:
+            hist_total = parallel.all_reduce_sum(rdf.read())
         allreduce_ms = (time.perf_counter() - ta) * 1e3
-        hist_total = h.cpu().numpy().astype(np.uint64)
+    else:
+        hist_total = rdf.read()
 
     total_frames = steps * fps * world
     value = total_frames / elapsed
@@ -269,7 +255,8 @@ def main() -> None:
         "config": {
             "workload": "RadialDistributionFunction, 10k-atom NaCl melt (5000 Na + 5000 Cl), "
                         "L=65, cutoff=32.4, 3240 bins, strict reference masks "
-                        "(BASELINE.json configs[1])",
+                        f"(BASELINE.json configs[1]); {steps * fps} frames per rank resident "
+                        "in HBM, each histogrammed once in the timed steps",
             "frames_per_step": fps,
             "frames_per_rank": steps * fps,
             "parallelism": f"frames sharded over {world} rank(s), one histogram all-reduce",
@@ -289,10 +276,11 @@ def main() -> None:
             result["gk_acf"] = gk_side_measurement(engine, args.gk_frames)
         if not args.skip_host_input:
             result["host_input"] = host_input_measurement(engine, fps)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    parallel.barrier()
+    transport = parallel.transport()
+    parallel.shutdown()
     if rank == 0:
+        result["config"]["transport"] = transport
         sys.stdout.flush()
         with os.fdopen(result_fd, "w") as result_stream:
             result_stream.write(json.dumps(result) + "\n")

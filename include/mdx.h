@@ -156,6 +156,40 @@ int mdx_rdf_accumulate(mdx_rdf_t handle, const void *const *species_pos, int dty
 /* Copy the histograms [n_keys][nbins] (uint64 counts) to the host; synchronises. */
 int mdx_rdf_read(mdx_rdf_t handle, uint64_t *hist);
 
+/* --------------------------------------------------------- multi-GPU exchange */
+/*
+ * The reference runs in one process on one device (its only device notion is
+ * mdsuite/utils/meta_functions.py:49-51); nothing of it is replaced here.  This is the
+ * one exchange step of the sharded calculators: one process per GPU, every rank
+ * histograms its atom-pair tiles (or frames), correlates its window origins, and the
+ * partial results are summed once per run by an RCCL all-reduce over xGMI.
+ *
+ * Rank 0 obtains a unique id (MDX_COMM_ID_BYTES opaque bytes) and hands it to the
+ * other ranks by any means; every rank then calls mdx_comm_create with the same id on
+ * the device it has selected with mdx_set_device.  librccl.so is opened at the first of
+ * these calls; mdx_comm_available returns 0 when that is not possible.
+ */
+typedef struct mdx_comm_s *mdx_comm_t;
+#define MDX_COMM_ID_BYTES 128
+#define MDX_COMM_U64 0
+#define MDX_COMM_I64 1
+#define MDX_COMM_F64 2
+#define MDX_COMM_SUM 0
+#define MDX_COMM_MAX 1
+int mdx_comm_available(void);
+int mdx_comm_unique_id(void *id, size_t bytes);
+int mdx_comm_create(mdx_comm_t *comm, int rank, int size, const void *id, size_t bytes);
+int mdx_comm_destroy(mdx_comm_t comm);
+int mdx_comm_rank(mdx_comm_t comm, int *rank, int *size);
+/* In-place all-reduce of `count` elements at `data` (MDX_HOST: staged through device
+ * memory; MDX_DEVICE: reduced where it lies).  Returns when the result is in place. */
+int mdx_comm_allreduce(mdx_comm_t comm, void *data, int location, int64_t count, int dtype,
+                       int op);
+/* Sum the accumulated histograms of all ranks in place on the device (uint64, exact in
+ * any order): afterwards mdx_rdf_read returns the total on every rank.  Accumulating
+ * further into a reduced handle would count the other ranks' share again. */
+int mdx_rdf_reduce(mdx_rdf_t handle, mdx_comm_t comm);
+
 /* -------------------------------------------------------- atom reductions */
 /*
  * out[t][c] (+)= sum_a w_a * x[a][t][c], accumulated in float64.

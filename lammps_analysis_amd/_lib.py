@@ -23,6 +23,13 @@ MDX_DEVICE = 1
 MDX_F32 = 0
 MDX_F64 = 1
 
+MDX_COMM_ID_BYTES = 128
+MDX_COMM_U64 = 0
+MDX_COMM_I64 = 1
+MDX_COMM_F64 = 2
+MDX_COMM_SUM = 0
+MDX_COMM_MAX = 1
+
 MDX_RDF_STRICT_REFERENCE_MASKS = 1
 MDX_RDF_LITERAL_KERNEL = 2
 
@@ -77,6 +84,16 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int64, c_i64_p,
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "mdx_rdf_read": (ctypes.c_int, [ctypes.c_void_p, c_u64_p]),
+    "mdx_comm_available": (ctypes.c_int, []),
+    "mdx_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "mdx_comm_create": (ctypes.c_int, [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_size_t]),
+    "mdx_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mdx_comm_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_int)]),
+    "mdx_comm_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "mdx_rdf_reduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "mdx_weighted_atom_sum": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                              c_f64_p, ctypes.c_double, ctypes.c_void_p,

@@ -21,7 +21,7 @@ LIB_PATH = LIB_DIR / "libmdx.so"
 OBJ_DIR = PACKAGE_DIR / "build"
 
 SOURCES = ["mdx_runtime.hip", "mdx_rdf.hip", "mdx_reduce.hip", "mdx_corr.hip",
-           "mdx_transform.hip", "mdx_adf.hip"]
+           "mdx_transform.hip", "mdx_adf.hip", "mdx_comm.hip"]
 
 HIPCC_FLAGS = [
     "-O3",
@@ -74,7 +74,7 @@ def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
         objects = list(pool.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB_PATH)]
-    cmd += [str(o) for o in objects]
+    cmd += [str(o) for o in objects] + ["-ldl"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"linking libmdx.so failed:\n{res.stdout}\n{res.stderr}")

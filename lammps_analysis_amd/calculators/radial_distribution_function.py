@@ -291,7 +291,7 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
                              for key in dict_keys]
                 # every rank sees the same frames and evaluates its share of pair tiles
                 rdf_engine.accumulate(positions, shard_rank=rank, shard_count=size)
-        histograms = parallel.all_reduce_sum(rdf_engine.read())
+        histograms = parallel.reduce_histograms(rdf_engine)  # the one exchange step
         rdf_engine.close()
         self.histograms = {key: histograms[i] for i, key in enumerate(self.key_list)}
         for i, key in enumerate(self.key_list):

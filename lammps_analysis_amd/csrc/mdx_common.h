@@ -124,6 +124,10 @@ struct KernelTimer {
   hipEvent_t stop_ = nullptr;
 };
 
+// In-place all-reduce of device memory on `stream` (asynchronous).
+int comm_allreduce_device(mdx_comm_s *comm, void *dptr, int64_t count, int dtype, int op,
+                          hipStream_t stream);
+
 inline size_t dtype_size(int dtype) { return dtype == MDX_F64 ? 8 : 4; }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -936,4 +936,15 @@ int mdx_rdf_read(mdx_rdf_t h, uint64_t *hist) {
   return MDX_OK;
 }
 
+int mdx_rdf_reduce(mdx_rdf_t h, mdx_comm_t comm) {
+  MDX_REQUIRE(h != nullptr && comm != nullptr, "null argument");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  MDX_TRY(comm_allreduce_device(comm, h->d_hist.ptr,
+                                static_cast<int64_t>(h->n_keys) * h->params.nbins,
+                                MDX_COMM_U64, MDX_COMM_SUM, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
 }  // extern "C"

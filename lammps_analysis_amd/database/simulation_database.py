@@ -24,9 +24,24 @@ import pathlib
 import typing
 from typing import List
 
+import functools
+
 import numpy as np
 
+from .. import parallel
+
 log = logging.getLogger(__name__)
+
+
+def _writer_only(method):
+    """Run a method that changes the store on the writing rank only; the other ranks of a
+    multi-GPU job wait until it is done (they all share one project directory)."""
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        return parallel.run_on_writer(lambda: method(self, *args, **kwargs))
+
+    return wrapper
 
 STORAGE_DTYPE = np.float32  # the reference's h5py datasets default to float32 (:491-497)
 
@@ -154,8 +169,9 @@ class Database:
         return (self._root / self.INDEX).exists()
 
     def initialize_database(self, structure: dict):
-        self.add_dataset(self._build_path_input(structure))
+        self.add_dataset(self._build_path_input(structure))  # collective, see _writer_only
 
+    @_writer_only
     def add_dataset(self, architecture: dict):
         """Create zero-filled datasets ``{path: shape}`` (append position 0)."""
         index = self._load_index()
@@ -171,6 +187,7 @@ class Database:
             index[dataset] = {"shape": list(shape), "starting_index": 0}
         self._save_index(index)
 
+    @_writer_only
     def resize_datasets(self, structure: dict):
         """Grow datasets along the configuration axis by the given amounts; unknown
         datasets are created (simulation_database.py:380-418 of the reference)."""
@@ -181,7 +198,7 @@ class Database:
                 raise TypeError("Invalid input for dataset generation")
             dataset = dataset.strip("/")
             if dataset not in index:
-                self.add_dataset({dataset: info})
+                Database.add_dataset.__wrapped__(self, {dataset: info})
                 index = self._load_index()
                 continue
             axis = 0 if len(info[:-1]) == 1 else 1
@@ -201,6 +218,7 @@ class Database:
 
     # -------------------------------------------------------------------- I/O
 
+    @_writer_only
     def add_data(self, chunk: TrajectoryChunkData):
         """Append a chunk at every dataset's append position, transposing from the
         chunk's time-first layout to the stored ``[particles, configurations, dims]``."""
@@ -285,6 +303,7 @@ class Database:
     def get_database_summary(self):
         return sorted({name.split("/")[0] for name in self._load_index()})
 
+    @_writer_only
     def change_key_names(self, mapping: dict):
         """Rename top-level groups."""
         index = self._load_index()

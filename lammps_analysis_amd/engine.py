@@ -252,6 +252,11 @@ class RdfEngine:
         check(_lib.load().mdx_rdf_read(self._handle, hist.ctypes.data_as(_lib.c_u64_p)))
         return hist
 
+    def reduce(self, comm) -> None:
+        """Sum the histograms of all ranks in place on the device (``mdx_rdf_reduce``);
+        ``comm`` is the ``mdx_comm_t`` handle of ``parallel.communicator()``."""
+        check(_lib.load().mdx_rdf_reduce(self._handle, comm))
+
     def reset(self) -> None:
         check(_lib.load().mdx_rdf_reset(self._handle))
 

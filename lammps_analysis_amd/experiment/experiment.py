@@ -90,7 +90,7 @@ class Experiment:
         self.figures_path = self.path / "figures"
         if not self.path.exists():
             log.info(f"Creating a new experiment ({self.name})!")
-            self.path.mkdir(parents=True)
+            self.path.mkdir(parents=True, exist_ok=True)
             self.figures_path.mkdir(exist_ok=True)
 
     # ------------------------------------------------------ persisted attributes

@@ -1,42 +1,366 @@
 """Multi-GPU sharding: one process per GPU, one exchange step per calculator run.
 
-The units of work are independent: atom-pair tiles or frames for the RDF, time
-origins (windows) for the correlations.  Every rank processes its share and the
-results are combined once at the end: integer histograms and correlation sums by
-one all-reduce, the per-window integral statistics by the parallel-variance merge.
-``torch.distributed`` is used only as the transport (backend ``nccl`` is RCCL over
-xGMI on ROCm; ``gloo`` on CPU for tests) and only if the caller has initialised
-it; a single process needs neither torch nor a collective.
+The units of work are independent: atom-pair tiles or frames for the RDF, frames for
+the atom reductions, time origins (windows) for the correlations.  Every rank processes
+its share and the results are combined once at the end: integer histograms and
+correlation sums by one all-reduce, the per-window integral statistics by the
+parallel-variance merge.  The reference itself is single-process
+(mdsuite/utils/meta_functions.py:49-51 is its only device notion).
 
-PyTorch-ROCm wheels carry their own HIP runtime.  A multi-GPU script must therefore
-``import torch`` (and initialise the process group) before the first calculator or
-engine call, which is when libmdx.so is loaded: the loader then binds libmdx to the
-HIP runtime torch already brought in, instead of starting a second one.
+Two transports, no third-party package:
+
+* ``rccl`` -- the all-reduce of libmdx (``mdx_comm_allreduce`` / ``mdx_rdf_reduce``:
+  RCCL over xGMI on device memory).  Used when every rank drives a GPU of its own.
+* ``host`` -- a star over a local socket: rank 0 collects, adds in rank order and sends
+  the sum back.  It carries the rendezvous (the 128-byte RCCL id), Python objects
+  (window moments) and barriers in every case, and the array sums when ranks share a
+  GPU or have none (tests).  Payloads are 10^4..10^5 bytes once per run.
+
+Ranks are described by the environment a launcher sets (``RANK``, ``LOCAL_RANK``,
+``WORLD_SIZE`` as ``python -m torch.distributed.run`` and most MPI-style launchers
+export them, or ``MDX_RANK`` / ``MDX_LOCAL_RANK`` / ``MDX_WORLD_SIZE``).  ``world()``
+initialises from it on first use; ``init()`` does so explicitly.  ``launch()`` starts
+the ranks of one node itself.
+
+File writes: every rank runs the same script against the same project directory, so
+only rank 0 (``is_writer()``) writes; ``run_on_writer`` makes the others wait.
 """
 from __future__ import annotations
 
+import atexit
+import ctypes
+import logging
+import os
+import pickle
+import socket
+import struct
+import subprocess
 import sys
-from typing import List, Tuple
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+log = logging.getLogger(__name__)
 
-def _dist():
-    torch = sys.modules.get("torch")
-    if torch is None:
+_CONNECT_TIMEOUT_S = float(os.environ.get("MDX_COMM_TIMEOUT", "180"))
+
+
+# ------------------------------------------------------------------ host channel
+
+
+def _send_msg(sock: socket.socket, payload: bytes) -> None:
+    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
+    chunks = []
+    while n:
+        part = sock.recv(min(n, 1 << 20))
+        if not part:
+            raise ConnectionError("peer closed the connection")
+        chunks.append(part)
+        n -= len(part)
+    return b"".join(chunks)
+
+
+def _recv_msg(sock: socket.socket) -> bytes:
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+def _parse_address(address: str):
+    """``unix:<name>`` (abstract socket, this node only) or ``tcp:<host>:<port>``."""
+    kind, _, rest = address.partition(":")
+    if kind == "unix":
+        return socket.AF_UNIX, "\0" + rest
+    if kind == "tcp":
+        host, _, port = rest.rpartition(":")
+        return socket.AF_INET, (host, int(port))
+    raise ValueError(f"bad rendezvous address '{address}' (unix:<name> or tcp:<host>:<port>)")
+
+
+class HostChannel:
+    """Star over stream sockets: rank 0 serves, ranks 1..n-1 each hold one connection."""
+
+    def __init__(self, rank: int, size: int, address: str):
+        self.rank, self.size, self.address = rank, size, address
+        family, target = _parse_address(address)
+        self._peers: List[Optional[socket.socket]] = [None] * size
+        self._server = None
+        if size == 1:
+            return
+        if rank == 0:
+            server = socket.socket(family, socket.SOCK_STREAM)
+            if family == socket.AF_INET:
+                server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            server.bind(target)
+            server.listen(size)
+            server.settimeout(_CONNECT_TIMEOUT_S)
+            self._server = server
+            for _ in range(size - 1):
+                try:
+                    conn, _addr = server.accept()
+                except socket.timeout:
+                    raise TimeoutError(f"rank 0 waited {_CONNECT_TIMEOUT_S:.0f} s for "
+                                       f"{size - 1} rank(s) at {address}") from None
+                conn.settimeout(None)
+                if family == socket.AF_INET:
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                peer = pickle.loads(_recv_msg(conn))
+                if not (0 < peer < size) or self._peers[peer] is not None:
+                    raise RuntimeError(f"unexpected rank {peer} at the rendezvous")
+                self._peers[peer] = conn
+        else:
+            deadline = time.monotonic() + _CONNECT_TIMEOUT_S
+            while True:
+                conn = socket.socket(family, socket.SOCK_STREAM)
+                try:
+                    conn.connect(target)
+                    break
+                except (ConnectionRefusedError, FileNotFoundError, OSError):
+                    conn.close()
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"rank {rank} could not reach rank 0 at "
+                                           f"{address}") from None
+                    time.sleep(0.05)
+            if family == socket.AF_INET:
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            _send_msg(conn, pickle.dumps(rank))
+            self._peers[0] = conn
+
+    def gather(self, obj) -> Optional[list]:
+        """Every rank's object in rank order on rank 0, None elsewhere."""
+        if self.size == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj]
+            for peer in range(1, self.size):
+                out.append(pickle.loads(_recv_msg(self._peers[peer])))
+            return out
+        _send_msg(self._peers[0], pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
         return None
-    dist = getattr(torch, "distributed", None)
-    if dist is None or not dist.is_available() or not dist.is_initialized():
-        return None
-    return dist
+
+    def bcast(self, obj):
+        """Rank 0's object on every rank."""
+        if self.size == 1:
+            return obj
+        if self.rank == 0:
+            payload = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+            for peer in range(1, self.size):
+                _send_msg(self._peers[peer], payload)
+            return obj
+        return pickle.loads(_recv_msg(self._peers[0]))
+
+    def allgather(self, obj) -> list:
+        return self.bcast(self.gather(obj))
+
+    def barrier(self) -> None:
+        self.allgather(None)
+
+    def close(self) -> None:
+        for conn in self._peers:
+            if conn is not None:
+                try:
+                    conn.close()
+                except OSError:
+                    pass
+        if self._server is not None:
+            self._server.close()
+        self._peers = [None] * self.size
+        self._server = None
+
+
+# ------------------------------------------------------------------------ state
+
+
+class _State:
+    def __init__(self):
+        self.initialised = False
+        self.rank = 0
+        self.size = 1
+        self.local_rank = 0
+        self.channel: Optional[HostChannel] = None
+        self.comm = None          # mdx_comm_t (c_void_p value) when the transport is rccl
+        self.transport = "none"   # "none" (one rank), "host", "rccl"
+        self.device_index: Optional[int] = None
+
+
+_state = _State()
+
+
+def _env_int(*names: str) -> Optional[int]:
+    for name in names:
+        value = os.environ.get(name)
+        if value not in (None, ""):
+            return int(value)
+    return None
+
+
+def default_address() -> str:
+    """Rendezvous address derived from the launcher's environment."""
+    address = os.environ.get("MDX_COMM_ADDR")
+    if address:
+        return address
+    # every rank of one launch has the launcher as its parent; the port tells
+    # concurrent launches of one user apart
+    port = os.environ.get("MASTER_PORT", "0")
+    return f"unix:mdx-{os.getuid()}-{port}-{os.getppid()}"
+
+
+def init(rank: Optional[int] = None, world_size: Optional[int] = None,
+         local_rank: Optional[int] = None, address: Optional[str] = None,
+         transport: Optional[str] = None) -> Tuple[int, int]:
+    """Join the ranks of this job; returns (rank, world size).
+
+    Selects GPU ``local_rank % device_count`` for this process (``config.device_index``),
+    connects the host channel and, when every rank has a GPU of its own, creates the RCCL
+    communicator.  ``transport`` (or ``MDX_COMM_TRANSPORT``): ``auto`` (default),
+    ``host``, ``rccl``.
+    """
+    if _state.initialised:
+        return _state.rank, _state.size
+    rank = _env_int("MDX_RANK", "RANK") if rank is None else rank
+    world_size = _env_int("MDX_WORLD_SIZE", "WORLD_SIZE") if world_size is None else world_size
+    local_rank = _env_int("MDX_LOCAL_RANK", "LOCAL_RANK") if local_rank is None else local_rank
+    rank = 0 if rank is None else int(rank)
+    world_size = 1 if world_size is None else int(world_size)
+    local_rank = rank if local_rank is None else int(local_rank)
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside a world of {world_size}")
+    transport = (transport or os.environ.get("MDX_COMM_TRANSPORT", "auto")).lower()
+    if transport not in ("auto", "host", "rccl"):
+        raise ValueError("transport must be auto, host or rccl")
+    _state.rank, _state.size, _state.local_rank = rank, world_size, local_rank
+    _state.initialised = True
+    if world_size == 1 and transport != "rccl":
+        _state.transport = "none"
+        return rank, world_size
+
+    from . import _lib
+    from .utils.config import config
+
+    n_devices = _lib.device_count()
+    if n_devices > 0:
+        _state.device_index = local_rank % n_devices
+        config.device_index = _state.device_index
+        _lib.check(_lib.load().mdx_set_device(_state.device_index))
+    _state.channel = HostChannel(rank, world_size, address or default_address())
+    _state.transport = "host"
+    atexit.register(shutdown)
+
+    # one GPU per rank and librccl present on every rank -> device collectives
+    lib = _lib.load()
+    mine = (socket.gethostname(), _state.device_index,
+            bool(n_devices > 0 and lib.mdx_comm_available()))
+    everyone = _state.channel.allgather(mine)
+    distinct = len({(h, d) for h, d, _ in everyone}) == world_size
+    usable = all(ok for _, _, ok in everyone) and distinct
+    if transport == "rccl" and not usable:
+        raise RuntimeError("MDX_COMM_TRANSPORT=rccl, but the ranks do not each own a GPU "
+                           f"with a loadable librccl.so: {everyone}")
+    if transport == "host" or not usable:
+        return rank, world_size
+    uid = ctypes.create_string_buffer(_lib.MDX_COMM_ID_BYTES)
+    if rank == 0:
+        _lib.check(lib.mdx_comm_unique_id(uid, _lib.MDX_COMM_ID_BYTES))
+    uid_bytes = _state.channel.bcast(uid.raw if rank == 0 else None)
+    handle = ctypes.c_void_p()
+    rc = lib.mdx_comm_create(ctypes.byref(handle), rank, world_size, uid_bytes,
+                             _lib.MDX_COMM_ID_BYTES)
+    error = None if rc == 0 else lib.mdx_last_error().decode("utf-8", "replace")
+    errors = _state.channel.allgather(error)
+    if any(e is not None for e in errors):
+        if rc == 0:
+            lib.mdx_comm_destroy(handle)
+        if transport == "rccl":
+            raise RuntimeError(f"RCCL communicator could not be created: {errors}")
+        log.warning("RCCL communicator could not be created (%s); sums go through the "
+                    "host channel", [e for e in errors if e])
+        return rank, world_size
+    _state.comm = handle.value
+    _state.transport = "rccl"
+    return rank, world_size
+
+
+def shutdown() -> None:
+    """Leave the job: destroys the communicator and closes the sockets."""
+    if not _state.initialised:
+        return
+    if _state.comm is not None:
+        from . import _lib
+        try:
+            _lib.load().mdx_comm_destroy(_state.comm)
+        except Exception:  # interpreter shutdown
+            pass
+        _state.comm = None
+    if _state.channel is not None:
+        _state.channel.close()
+        _state.channel = None
+    _state.__init__()
+
+
+def _ensure() -> None:
+    if _state.initialised:
+        return
+    size = _env_int("MDX_WORLD_SIZE", "WORLD_SIZE")
+    if size is not None and size > 1:
+        init()
+    else:
+        _state.initialised = True
 
 
 def world() -> Tuple[int, int]:
-    """(rank, world size); (0, 1) when no process group is initialised."""
-    dist = _dist()
-    if dist is None:
-        return 0, 1
-    return dist.get_rank(), dist.get_world_size()
+    """(rank, world size); (0, 1) for a process started without a launcher."""
+    _ensure()
+    return _state.rank, _state.size
+
+
+def transport() -> str:
+    _ensure()
+    return _state.transport
+
+
+def communicator():
+    """The ``mdx_comm_t`` handle of this rank, or None (one rank, or host transport)."""
+    _ensure()
+    return _state.comm
+
+
+def is_writer() -> bool:
+    """True on the one rank that writes project files and datasets."""
+    return world()[0] == 0
+
+
+def barrier() -> None:
+    _ensure()
+    if _state.channel is not None:
+        _state.channel.barrier()
+
+
+def run_on_writer(fn: Callable[[], object]):
+    """Run ``fn`` on rank 0 while the other ranks wait; its result (or its failure) is
+    delivered to every rank."""
+    _ensure()
+    if _state.size == 1:
+        return fn()
+    # nobody is still reading what the writer is about to change
+    _state.channel.barrier()
+    outcome = None
+    if _state.rank == 0:
+        try:
+            outcome = ("ok", fn())
+        except BaseException as exc:  # delivered to all ranks below
+            outcome = ("error", f"{type(exc).__name__}: {exc}")
+            _state.channel.bcast(outcome)
+            raise
+    outcome = _state.channel.bcast(outcome)
+    if outcome[0] == "error":
+        raise RuntimeError(f"rank 0 failed: {outcome[1]}")
+    return outcome[1]
+
+
+# ------------------------------------------------------------------- partitions
 
 
 def split_range(n: int, rank: int, size: int) -> Tuple[int, int]:
@@ -52,41 +376,72 @@ def split_frames(frames: np.ndarray, rank: int, size: int) -> np.ndarray:
     return frames[begin:end]
 
 
-def _device_for_backend(dist):
-    if dist.get_backend() == "nccl":
-        import torch
-        return torch.device("cuda", torch.cuda.current_device())
-    return None
+# ------------------------------------------------------------------ collectives
+
+_REDUCIBLE = {np.dtype(np.uint64): 0, np.dtype(np.int64): 1, np.dtype(np.float64): 2}
+
+
+def _all_reduce(array: np.ndarray, op: str) -> np.ndarray:
+    _ensure()
+    if _state.size == 1:
+        return array
+    arr = np.ascontiguousarray(array)
+    if _state.comm is not None:
+        from . import _lib
+        work = arr if arr.dtype in _REDUCIBLE else arr.astype(
+            np.float64 if arr.dtype.kind == "f" else np.int64)
+        work = work.copy()
+        _lib.check(_lib.load().mdx_comm_allreduce(
+            _state.comm, work.ctypes.data, _lib.MDX_HOST, work.size, _REDUCIBLE[work.dtype],
+            _lib.MDX_COMM_SUM if op == "sum" else _lib.MDX_COMM_MAX))
+        return work.astype(arr.dtype, copy=False)
+    parts = _state.channel.gather(arr)
+    total = None
+    if _state.rank == 0:
+        total = parts[0].copy()
+        for part in parts[1:]:  # rank order: the same sum on every run
+            if op == "sum":
+                total += part
+            else:
+                np.maximum(total, part, out=total)
+    return _state.channel.bcast(total)
 
 
 def all_reduce_sum(array: np.ndarray) -> np.ndarray:
-    """Element-wise sum over ranks (identity without a process group).
+    """Element-wise sum over ranks (the array itself for one rank)."""
+    return _all_reduce(array, "sum")
 
-    uint64 histograms travel as int64: counts stay far below 2**63.
-    """
-    dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
-        return array
-    import torch
-    arr = np.ascontiguousarray(array)
-    as_int = arr.dtype == np.uint64
-    t = torch.from_numpy(arr.view(np.int64) if as_int else arr.copy())
-    device = _device_for_backend(dist)
-    if device is not None:
-        t = t.to(device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    out = t.cpu().numpy()
-    return out.view(np.uint64) if as_int else out
+
+def all_reduce_max(array) -> np.ndarray:
+    """Element-wise maximum over ranks."""
+    return _all_reduce(np.asarray(array, dtype=np.float64), "max")
+
+
+def reduce_histograms(rdf_engine) -> np.ndarray:
+    """Total pair histograms of an ``engine.RdfEngine`` over all ranks, on every rank:
+    in place on the devices (``mdx_rdf_reduce``) with the rccl transport, else through
+    the host channel."""
+    _ensure()
+    if _state.size > 1 and _state.comm is not None:
+        rdf_engine.reduce(_state.comm)
+        return rdf_engine.read()
+    return all_reduce_sum(rdf_engine.read())
 
 
 def all_gather_objects(obj) -> List:
     """Every rank's object, in rank order."""
-    dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
+    _ensure()
+    if _state.size == 1:
         return [obj]
-    out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, obj)
-    return out
+    return _state.channel.allgather(obj)
+
+
+def broadcast_object(obj):
+    """Rank 0's object on every rank."""
+    _ensure()
+    if _state.size == 1:
+        return obj
+    return _state.channel.bcast(obj)
 
 
 def merge_moments(moments):
@@ -97,3 +452,50 @@ def merge_moments(moments):
             continue
         merged = part if merged is None else merged.merge(part)
     return merged
+
+
+# --------------------------------------------------------------------- launcher
+
+
+def launch(argv: Sequence[str], n_ranks: int, env: Optional[dict] = None,
+           timeout: Optional[float] = None) -> int:
+    """Start ``n_ranks`` copies of ``python argv...`` on this node, one per GPU, and wait.
+
+    The parent makes no GPU call.  Rank r gets ``MDX_RANK`` / ``MDX_LOCAL_RANK`` = r,
+    ``MDX_WORLD_SIZE`` and a rendezvous address of its own; stdout and stderr are
+    inherited.  Returns the first non-zero exit status (0 when all ranks succeeded); the
+    remaining ranks are terminated when one fails.
+    """
+    base = dict(os.environ if env is None else env)
+    for name in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        base.pop(name, None)
+    base["MDX_WORLD_SIZE"] = str(int(n_ranks))
+    base["MDX_COMM_ADDR"] = f"unix:mdx-launch-{os.getpid()}-{time.monotonic_ns()}"
+    procs = []
+    for r in range(int(n_ranks)):
+        child = dict(base, MDX_RANK=str(r), MDX_LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, *argv], env=child))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    status = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and status == 0:
+                status = rc
+        if status != 0 or (deadline is not None and time.monotonic() > deadline):
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if status == 0:
+                status = 124
+            break
+        time.sleep(0.02)
+    return status

@@ -16,6 +16,7 @@ from datetime import datetime
 from pathlib import Path
 from typing import Dict, Union
 
+from .. import parallel
 from ..database import scheme as db
 from ..experiment.experiment import Experiment
 from ..experiment.run import RunComputation
@@ -67,6 +68,8 @@ class ResultStore:
         self._save()
 
     def _save(self) -> None:
+        if not parallel.is_writer():  # every rank holds the results in memory
+            return
         raw = [{"name": c.name, "experiment": c.experiment_name,
                 "attributes": c.computation_parameter,
                 "results": [r.to_json() for r in c.computation_results]}
@@ -86,6 +89,9 @@ class Project:
         self.project_dir = Path(f"{self.storage_path}/{self.name}")
         self.project_dir.mkdir(parents=True, exist_ok=True)
         self.attach_file_logger()
+        # ranks of a multi-GPU job share the directory: all of them read the state the
+        # previous run left before the writing rank touches it
+        parallel.barrier()
         self._state_file = self.project_dir / "project.json"
         self._state = {"description": description, "experiments": {}}
         if self._state_file.exists():
@@ -97,6 +103,7 @@ class Project:
         else:
             log.info(f"Creating new project {self.name}")
         self.results = ResultStore(self.project_dir / "results.json")
+        parallel.barrier()
         self.save_state()
 
     # ----------------------------------------------------------------- state
@@ -114,6 +121,8 @@ class Project:
         return self._state["experiments"].setdefault(name, {})
 
     def save_state(self) -> None:
+        if not parallel.is_writer():
+            return
         tmp = self._state_file.with_suffix(".tmp")
         with open(tmp, "w") as fh:
             json.dump(self._state, fh)

@@ -16,6 +16,7 @@ import typing
 
 import numpy as np
 
+from .. import parallel
 from ..database.data_manager import DataManager
 from ..database.simulation_database import (Database, PropertyInfo, SpeciesInfo,
                                             TrajectoryChunkData)
@@ -241,7 +242,14 @@ class SingleSpeciesTrafo(Transformations):
 
 
 class MultiSpeciesTrafo(Transformations):
-    """Transformations that combine all species into one system property."""
+    """Transformations that combine all species into one system property.
+
+    Every output frame depends on that frame alone, so with several ranks (one per GPU)
+    each rank reduces a contiguous share of every batch's frames and the shares are
+    gathered in rank order before the writing rank stores the batch; a subclass whose
+    frames depend on earlier ones (a ``carryover``) sets ``frame_shardable = False``."""
+
+    frame_shardable = True
 
     def run_transformation(self, species: typing.Iterable[str] = None) -> None:
         if species is None:
@@ -260,16 +268,34 @@ class MultiSpeciesTrafo(Transformations):
         for index, batch_dict in enumerate(batch_generator(*batch_generator_args)):
             batch_dict.pop(str.encode("data_size"))
             hierarchical = {sp_name: {} for sp_name in species}
+            rank, size = parallel.world()
+            shard = size > 1 and self.frame_shardable
+            begin = end = None
             for key, val in batch_dict.items():
                 sp_name, prop_name = key.decode().split("/")
+                if shard:
+                    # this rank's frames of the batch (a view of the stored array)
+                    begin, end = parallel.split_range(val.shape[1], rank, size)
+                    val = val[:, begin:end]
                 hierarchical[sp_name][prop_name] = val
             for sp_name in hierarchical:
                 hierarchical[sp_name].update(const_input_data[sp_name])
-            ret = self.transform_batch(hierarchical, carryover=carryover)
-            if isinstance(ret, tuple):
-                transformed_batch, carryover = ret
+            if shard:
+                if end > begin:
+                    part = self.transform_batch(hierarchical, carryover=None)
+                    if isinstance(part, tuple):
+                        raise RuntimeError(f"{type(self).__name__} carries state between "
+                                           "batches and cannot shard frames over ranks")
+                    part = np.asarray(part, dtype=np.float64)
+                else:
+                    part = np.zeros((0, self.output_property.n_dims))
+                transformed_batch = np.concatenate(parallel.all_gather_objects(part), axis=0)
             else:
-                transformed_batch = ret
+                ret = self.transform_batch(hierarchical, carryover=carryover)
+                if isinstance(ret, tuple):
+                    transformed_batch, carryover = ret
+                else:
+                    transformed_batch = ret
             self._save_output(data=transformed_batch, data_structure=output_data_structure,
                               index=index * self.batch_size)
 
