@@ -124,6 +124,10 @@ typedef struct mdx_rdf_s *mdx_rdf_t;
  * (IEEE divide, rint, sqrt, float64 bin divide) instead of the table-driven
  * kernel that is proven equal to it; for validation. */
 #define MDX_RDF_LITERAL_KERNEL 2u
+/* Use the table-driven kernel (exact float32 squared distance, bin from thresholds) for
+ * every frame instead of the faster kernel that evaluates an error-bounded approximation
+ * and resolves the pairs near a bin edge literally; for validation. */
+#define MDX_RDF_TABLE_KERNEL 4u
 
 /*
  * n_per_species[s] atoms of species s, in the order the calculator concatenates

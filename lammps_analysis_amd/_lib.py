@@ -32,6 +32,7 @@ MDX_COMM_MAX = 1
 
 MDX_RDF_STRICT_REFERENCE_MASKS = 1
 MDX_RDF_LITERAL_KERNEL = 2
+MDX_RDF_TABLE_KERNEL = 4
 
 
 class MdxError(RuntimeError):

@@ -6,12 +6,17 @@
 //      X[frame][component][slot] whose slots are grouped in tiles of 256 atoms,
 //      one species per tile, padded with NaN (a NaN coordinate can never pass the
 //      cutoff test, so padding needs no bounds checks in the pair loop);
-//   2. tile kernel: one 256-thread block per (tile pair, frame group).  Each lane
-//      keeps one i-atom in registers, the j-tile is staged in LDS and read as a
-//      broadcast, the species-pair histogram lives in LDS (ds_add_u32) and is
-//      flushed once per block with 64-bit global atomics.
+//   2. pair kernel.  Each lane keeps one i-atom in registers; the 256 j-atoms of the
+//      tile are the same for every lane and come through wave-uniform scalar loads
+//      straight from the packed image; the species-pair histogram lives in LDS
+//      (ds_add_u32) and is flushed with 64-bit global atomics.
+//        rdf_fast_kernel  (default): persistent blocks, each walking a contiguous,
+//          cost-balanced range of (tile pair, frame) items and flushing its histogram
+//          only when the species-pair key changes;
+//        rdf_tile_kernel  : one block per (tile pair, frame group); the literal
+//          kernel, the table kernel for frames the fast kernel leaves out.
 //
-// Two pair functions produce identical bins:
+// Three pair functions produce identical bins:
 //   literal : the reference's float32 operations one by one (IEEE divide, rint,
 //             separate multiply/subtract, (x*x+y*y)+z*z, IEEE sqrt, d < cutoff,
 //             float64 divide by the bin width, min, truncation);
@@ -31,6 +36,14 @@
 //                 nbins/cutoff); only when that product lies within the error
 //                 bound of an integer does it consult the two neighbouring
 //                 thresholds (kept in LDS).
+//   fast    : the table kernel still spends most of its instructions on reproducing
+//             the literal roundings of every pair.  The fast loop drops that: it
+//             evaluates an approximation of the bin position whose distance from the
+//             literal one is bounded on the host (rdf_fast_setup), and only pairs
+//             whose position lies within that bound of a bin edge (well under 1 %)
+//             are evaluated again, literally, against the thresholds.  Those pairs
+//             are noted in a lane-private LDS queue and corrected after the j loop,
+//             so the hot loop has no divergent slow path.
 //
 // This file must be compiled with -ffp-contract=off: a fused multiply-add in the
 // minimum-image or the squared-distance expression changes the rounding and
@@ -53,6 +66,8 @@ struct TilePair {
   int32_t tile_j;
   int32_t key;
   int32_t diagonal;  // 1: same tile on both sides, only j > i counts
+  int32_t j_count;   // atoms in the j tile (the rest of its 256 slots is padding)
+  int32_t pad_[3];   // 32 bytes: an entry is fetched with two 16-byte scalar loads
 };
 
 struct RdfParams {
@@ -67,6 +82,15 @@ struct RdfParams {
   float edge_eps2;     // twice that
   double step;         // double(cutoff - 0.0f) / double(nbins)
   int nbins;
+  // fast kernel (rdf_fast_setup)
+  float half_box[3];   // box / 2, exact
+  float fast_magic;    // 2^k + shift: adding it leaves the bin position in the mantissa
+  uint32_t fast_frac_bits;   // F = 23 - k fraction bits
+  uint32_t fast_addr_mask;   // ((1 << k) - 1) << 2: byte offset of the bin's LDS word
+  uint32_t fast_frac_mask;   // (1 << F) - 1
+  uint32_t fast_edge_units;  // E: a fraction below E grid units means "near an edge"
+  uint32_t fast_keep_bits;   // float bits below this: position < nbins + E grid units
+  int fast_ok;               // 0: the bound is too wide for this geometry, do not use
 };
 
 // ---------------------------------------------------------------- pack kernel
@@ -300,6 +324,264 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
   }
 }
 
+
+// ----------------------------------------------------------------- fast kernel
+
+// Bits of the float that holds the approximate bin position of one pair, for frames
+// whose coordinate differences stay below t_far ("wrapped" frames).
+//   r = x_j - x_i (the literal difference), then per component
+//   m = h - ||r| - h|,  h = box / 2      (= min(|r|, box - |r|) up to two roundings)
+//   s = fma(mz, mz, fma(my, my, mx * mx)),  root = v_sqrt_f32(s)       (1 ulp)
+//   result = bits(fma(root, nbins / cutoff, 2^k + shift))
+// Adding 2^k moves the position's integer part into mantissa bits [F, 23) and its
+// fraction, rounded to 2^-F, into bits [0, F).  rdf_fast_setup bounds the distance
+// of that position from the literal one by `shift`.  The same function, with the same
+// operations, is evaluated by the hot loop (two pairs per packed instruction) and by
+// the correction pass; IEEE fma / multiply and the deterministic v_sqrt_f32 give both
+// the same bits.
+__device__ __forceinline__ uint32_t fast_position_bits(float xi, float yi, float zi, float xj,
+                                                       float yj, float zj, float hx, float hy,
+                                                       float hz, float scale, float magic) {
+  const float rx = xj - xi, ry = yj - yi, rz = zj - zi;
+  const float mx = hx - fabsf(fabsf(rx) - hx);
+  const float my = hy - fabsf(fabsf(ry) - hy);
+  const float mz = hz - fabsf(fabsf(rz) - hz);
+  const float s = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+  return __float_as_uint(__builtin_fmaf(__builtin_amdgcn_sqrtf(s), scale, magic));
+}
+
+// Literal squared distance of a pair in a wrapped frame (see table_tile_loop).
+__device__ __forceinline__ float literal_wrapped_s(float xi, float yi, float zi, float xj,
+                                                   float yj, float zj, const RdfParams &p) {
+  const float rx = xj - xi, ry = yj - yi, rz = zj - zi;
+  const float ax = fminf(fabsf(rx), p.box[0] - fabsf(rx));
+  const float ay = fminf(fabsf(ry), p.box[1] - fabsf(ry));
+  const float az = fminf(fabsf(rz), p.box[2] - fabsf(rz));
+  return (ax * ax + ay * ay) + az * az;
+}
+
+// A value the compiler must keep in a vector register: the simple float32 / integer
+// vector instructions issue at half their rate when one operand is a scalar register.
+__device__ __forceinline__ float in_vgpr(float v) {
+  float out;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(out) : "s"(v));
+  return out;
+}
+__device__ __forceinline__ uint32_t in_vgpr(uint32_t v) {
+  uint32_t out;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(out) : "s"(v));
+  return out;
+}
+
+// h - ||r| - h| with the absolute values as operand modifiers: two plain v_sub_f32 with
+// register operands (the compiler's own choice packs the subtractions and pays for the
+// absolute values with separate v_and_b32).
+__device__ __forceinline__ float fold_half(float r, float h) {
+  float t, m;
+  asm("v_sub_f32_e64 %0, |%1|, %2" : "=v"(t) : "v"(r), "v"(h));
+  asm("v_sub_f32_e64 %0, %2, |%1|" : "=v"(m) : "v"(t), "v"(h));
+  return m;
+}
+
+// hist[byte_offset / 4] += value for a histogram that starts at LDS address 0 (the
+// kernel has no static LDS, so its dynamic array does; mdx_rdf_create checks that).
+// Spares the v_add_u32 of the array's base address per pair.
+__device__ __forceinline__ void lds_count(uint32_t byte_offset, uint32_t value) {
+  asm volatile("ds_add_u32 %0, %1" : : "v"(byte_offset), "v"(value) : "memory");
+}
+
+constexpr int kQueueSlots = 8;  // near-edge pairs a lane can note before they are resolved
+
+// Resolves the noted pairs of every lane: the hot loop has already counted them in the
+// bin of the approximate position (if that was below the cutoff); here the literal
+// squared distance decides, and the count is moved when the two disagree.
+__device__ __forceinline__ void fast_resolve_queue(
+    int &count, uint8_t *__restrict__ queue, float xi, float yi, float zi,
+    const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
+    float hx, float hy, float hz, float scale, float magic, uint32_t *__restrict__ hist,
+    const float *__restrict__ g_thr, const RdfParams &p) {
+  while (__any(count > 0)) {
+    if (count > 0) {
+      --count;
+      const int j = queue[count];
+      const float pxj = xj[j], pyj = yj[j], pzj = zj[j];
+      const uint32_t bits =
+          fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic);
+      const bool counted = bits < p.fast_keep_bits;
+      const int guess = static_cast<int>((bits & 0x7FFFFFu) >> p.fast_frac_bits);
+      const float s = literal_wrapped_s(xi, yi, zi, pxj, pyj, pzj, p);
+      int e = min(max(guess, 0), p.nbins - 1);
+      const float lo = g_thr[e];
+      const float hi = g_thr[e + 1];
+      e += (s >= hi) ? 1 : 0;
+      e -= (s < lo) ? 1 : 0;
+      const bool kept = s < p.s_cut;
+      if (counted && !(kept && e == guess)) atomicSub(&hist[guess], 1u);
+      if (kept && !(counted && e == guess)) atomicAdd(&hist[e], 1u);
+    }
+  }
+}
+
+// One (tile pair, frame) item: lane = i-atom, loop over the j-atoms of the tile.
+template <bool kDiag>
+__device__ __forceinline__ void fast_tile_loop(
+    float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
+    const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
+    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
+    uint32_t frac_mask, uint32_t one) {
+  const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
+  const int j_end = (j_count + 3) & ~3;  // padding slots hold NaN and are never counted
+  if (j_begin >= j_end) return;
+  const uint32_t shift = in_vgpr(p.fast_frac_bits - 2u);
+  const uint32_t edge = p.fast_edge_units;
+  const uint32_t keep_bits = p.fast_keep_bits;
+  const v2f xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
+  const v2f scale2 = {scale, scale}, magic2 = {magic, magic};
+  int count = 0;
+  float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
+  float4 ny = *reinterpret_cast<const float4 *>(yj + j_begin);
+  float4 nz = *reinterpret_cast<const float4 *>(zj + j_begin);
+  for (int j0 = j_begin; j0 < j_end; j0 += 4) {
+    const float4 cx = nx, cy = ny, cz = nz;
+    const int jn = (j0 + 4 < j_end) ? j0 + 4 : j0;
+    nx = *reinterpret_cast<const float4 *>(xj + jn);
+    ny = *reinterpret_cast<const float4 *>(yj + jn);
+    nz = *reinterpret_cast<const float4 *>(zj + jn);
+    const float pxs[4] = {cx.x, cx.y, cx.z, cx.w};
+    const float pys[4] = {cy.x, cy.y, cy.z, cy.w};
+    const float pzs[4] = {cz.x, cz.y, cz.z, cz.w};
+    uint32_t bits[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const v2f rx = v2f{pxs[2 * h], pxs[2 * h + 1]} - xi2;
+      const v2f ry = v2f{pys[2 * h], pys[2 * h + 1]} - yi2;
+      const v2f rz = v2f{pzs[2 * h], pzs[2 * h + 1]} - zi2;
+      v2f mx, my, mz;
+      mx.x = fold_half(rx.x, hx);
+      mx.y = fold_half(rx.y, hx);
+      my.x = fold_half(ry.x, hy);
+      my.y = fold_half(ry.y, hy);
+      mz.x = fold_half(rz.x, hz);
+      mz.y = fold_half(rz.y, hz);
+      const v2f s2 = __builtin_elementwise_fma(mz, mz, __builtin_elementwise_fma(my, my, mx * mx));
+      const v2f root = {__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
+      const v2f t2 = __builtin_elementwise_fma(root, scale2, magic2);
+      bits[2 * h] = __float_as_uint(t2.x);
+      bits[2 * h + 1] = __float_as_uint(t2.y);
+    }
+    bool keep[4], near[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      keep[u] = bits[u] < keep_bits;  // a NaN (padding) compares above every position
+      if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
+      near[u] = keep[u] && ((bits[u] & frac_mask) < edge);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (keep[u]) lds_count((bits[u] >> shift) & addr_mask, one);
+    }
+    if (__builtin_expect(near[0] || near[1] || near[2] || near[3], 0)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (near[u]) {
+          queue[count] = static_cast<uint8_t>(j0 + u);
+          ++count;
+        }
+      }
+      // a lane has room for four more pairs or everything is resolved now
+      if (__any(count > kQueueSlots - 4))
+        fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
+                           hist, g_thr, p);
+    }
+  }
+  fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
+                     g_thr, p);
+}
+
+// Persistent blocks with a shared work counter.  A chunk is up to frames_per_chunk
+// consecutive frames of one tile pair, numbered pair * chunks_per_pair + group with the
+// tile pairs in key order.  Every block claims the next chunk with one global atomic
+// until none is left, so the blocks drain the launch together whatever their pace, and
+// since they all move through the keys in step a block flushes its LDS histogram only
+// a few times per launch (on a key change and at the end).  Frames that are not
+// "wrapped" are skipped (the table kernel takes them).
+// LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
+__global__ __launch_bounds__(kTile) void rdf_fast_kernel(
+    const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
+    int chunks_per_pair, int n_chunks, const TilePair *__restrict__ pairs,
+    unsigned int *__restrict__ work_counter, RdfParams p, const float *__restrict__ g_thr,
+    const int32_t *__restrict__ frame_wrapped, int lds_hist_words,
+    unsigned long long *__restrict__ g_hist) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
+  const int tid = threadIdx.x;
+  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueSlots;
+  uint32_t *claim = reinterpret_cast<uint32_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words) +
+                                                 static_cast<size_t>(kTile) * kQueueSlots);
+
+  const float hx = in_vgpr(p.half_box[0]);
+  const float hy = in_vgpr(p.half_box[1]);
+  const float hz = in_vgpr(p.half_box[2]);
+  const float scale = p.inv_step;
+  const float magic = in_vgpr(p.fast_magic);
+  const uint32_t addr_mask = in_vgpr(p.fast_addr_mask);
+  const uint32_t frac_mask = in_vgpr(p.fast_frac_mask);
+  const uint32_t one = in_vgpr(1u);
+
+  int cur_key = -1;
+  for (;;) {
+    if (tid == 0) *claim = atomicAdd(work_counter, 1u);
+    __syncthreads();
+    const uint32_t chunk = *claim;
+    __syncthreads();  // everyone has read the claim before thread 0 writes the next
+    if (chunk >= static_cast<uint32_t>(n_chunks)) break;
+    const int pair_index = static_cast<int>(chunk / static_cast<uint32_t>(chunks_per_pair));
+    const int group = static_cast<int>(chunk - pair_index * static_cast<uint32_t>(chunks_per_pair));
+    const TilePair tp = pairs[pair_index];
+    if (tp.key != cur_key) {
+      if (cur_key >= 0) {
+        unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
+        for (int b = tid; b < p.nbins; b += kTile) {
+          const uint32_t v = hist[b];
+          if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
+        }
+        __syncthreads();
+      }
+      for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
+      __syncthreads();
+      cur_key = tp.key;
+    }
+    const int f_begin = group * frames_per_chunk;
+    const int f_end = min(n_frames, f_begin + frames_per_chunk);
+    const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
+    for (int f = f_begin; f < f_end; ++f) {
+      if (frame_wrapped[f] == 0) continue;
+      const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
+      const float xi = X[slot_i];
+      const float yi = X[n_pad + slot_i];
+      const float zi = X[2 * n_pad + slot_i];
+      const float *xj = X + static_cast<int64_t>(tp.tile_j) * kTile;
+      const float *yj = xj + n_pad;
+      const float *zj = yj + n_pad;
+      if (tp.diagonal)
+        fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid, hx,
+                             hy, hz, scale, magic, addr_mask, frac_mask, one);
+      else
+        fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid, hx,
+                              hy, hz, scale, magic, addr_mask, frac_mask, one);
+    }
+    __syncthreads();  // the chunk's counts are in before a flush or the next claim
+  }
+  if (cur_key >= 0) {
+    unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
+    for (int b = tid; b < p.nbins; b += kTile) {
+      const uint32_t v = hist[b];
+      if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- tile kernel
 
 // LDS layout: uint32 hist[lds_hist_words] | float thresholds[lds_thr_words] (table
@@ -309,7 +591,8 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_group,
     const TilePair *__restrict__ pairs, RdfParams p,
     const float *__restrict__ g_thresholds, const int32_t *__restrict__ frame_wrapped,
-    int lds_hist_words, int lds_thr_words, unsigned long long *__restrict__ g_hist) {
+    int lds_hist_words, int lds_thr_words, unsigned long long *__restrict__ g_hist,
+    int only_unwrapped) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   float *thr = reinterpret_cast<float *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words));
@@ -320,6 +603,12 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
   const TilePair tp = pairs[blockIdx.x];
   const int f_begin = blockIdx.y * frames_per_group;
   const int f_end = min(n_frames, f_begin + frames_per_group);
+  if (!kLiteral && only_unwrapped) {
+    // complement of the fast kernel: most launches have nothing to do here
+    bool any = false;
+    for (int f = f_begin; f < f_end; ++f) any = any || (frame_wrapped[f] == 0);
+    if (!any) return;
+  }
 
   for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
   if (!kLiteral) {
@@ -355,6 +644,7 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
       const float *yj = xj + n_pad;
       const float *zj = yj + n_pad;
       const bool wrapped = frame_wrapped[f] != 0;
+      if (wrapped && only_unwrapped) continue;
       if (tp.diagonal) {
         if (wrapped)
           table_tile_loop<true, true>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
@@ -439,6 +729,54 @@ inline float first_a_reaching(float target, float box) {
   return bits_float(hi);
 }
 
+// Parameters of the fast kernel and the bound that makes it exact.
+//
+// For a pair in a wrapped frame (|r_c| < t_far_c, about 1.5 box lengths) let pos_lit =
+// double(d_lit) / step be the position the literal sequence bins, and P the number the
+// fast loop forms before adding 2^k + shift (fast_position_bits).  With u = 2^-24:
+//   * per component |m - m_lit| <= 2 u L_c: t = |r| - h rounds by at most u |t| < u L_c,
+//     m = h - |t| by at most u h = u L_c / 2, the literal L_c - |r| by at most u L_c / 2,
+//     and h - ||r| - h| = min(|r|, L_c - |r|) exactly (h = L_c / 2 is exact);
+//     hence the two exact norms differ by at most A = 2 u |L|;
+//   * both squared sums carry three roundings (relative 3 u), a square root halves that,
+//     v_sqrt_f32 is good to one ulp (2 u), the literal sqrtf to u / ... ; the scale
+//     nbins / cutoff is rounded once: |P - pos_lit| <= A / step + 9 u pos;
+//   * the addition rounds to the grid 2^-F: at most 2^-(F+1) more.
+// delta is the sum for pos <= nbins + 2 (plus 1e-6 for the top edge, which the literal
+// rule places at double(cutoff) / step rather than at nbins).  With shift >= delta the
+// stored position lies in [pos_lit, pos_lit + 2 shift]: its integer part is the literal
+// bin unless its fraction is below 2 shift, and exactly those pairs are resolved
+// literally.
+void rdf_fast_setup(RdfParams &p) {
+  p.fast_ok = 0;
+  for (int c = 0; c < 3; ++c) {
+    p.half_box[c] = p.box[c] * 0.5f;
+    if (p.half_box[c] * 2.0f != p.box[c]) return;  // not exact (denormal box)
+    if (p.t_far[c] <= 0.0f) return;                // no frame may use the wrapped form
+  }
+  int k = 1;
+  while ((1 << k) < p.nbins + 3) ++k;
+  if (k > 15) return;
+  const int frac_bits = 23 - k;
+  const double u = 0x1p-24;
+  const double norm_l = std::sqrt(static_cast<double>(p.box[0]) * p.box[0] +
+                                  static_cast<double>(p.box[1]) * p.box[1] +
+                                  static_cast<double>(p.box[2]) * p.box[2]);
+  const double grid = std::ldexp(1.0, -frac_bits);
+  const double delta = 2.0 * u * norm_l / p.step + 9.0 * u * (p.nbins + 2.0) + 0.5 * grid + 1e-6;
+  const double units = std::ceil(delta / grid);
+  if (2.0 * units > 0.125 / grid) return;  // more than one pair in eight would be resolved
+  const uint32_t shift_units = static_cast<uint32_t>(units);
+  p.fast_frac_bits = static_cast<uint32_t>(frac_bits);
+  p.fast_addr_mask = ((1u << k) - 1u) << 2;
+  p.fast_frac_mask = (1u << frac_bits) - 1u;
+  p.fast_edge_units = 2u * shift_units;
+  p.fast_magic = static_cast<float>(std::ldexp(1.0, k) + shift_units * grid);  // exact
+  const float top = static_cast<float>(std::ldexp(1.0, k) + p.nbins);
+  p.fast_keep_bits = float_bits(top) + p.fast_edge_units;
+  p.fast_ok = 1;
+}
+
 }  // namespace
 
 struct mdx_rdf_s {
@@ -455,7 +793,10 @@ struct mdx_rdf_s {
   int lds_thr_words = 0;
   size_t lds_bytes = 0;
   DeviceBuffer d_pairs, d_pairs_shard, d_hist, d_thresholds, d_slot_species, d_slot_atom;
-  DeviceBuffer d_species_ptr, d_frames, d_packed, d_wrapped;
+  DeviceBuffer d_species_ptr, d_frames, d_packed, d_wrapped, d_counter;
+  int fast_blocks = 0;             // persistent grid of the fast kernel
+  size_t fast_lds_bytes = 0;
+  int fast_lds_hist_words = 0;
   int shard_rank = 0, shard_count = 1;
   int64_t n_pairs_shard = 0;
   std::vector<const void *> uploaded_ptrs;  // content of d_species_ptr
@@ -523,33 +864,60 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
                        h->d_wrapped.as<int32_t>());
     MDX_HIP(hipGetLastError());
   }
-  // frames per block: large enough to amortise the histogram flush, small enough
-  // that the last round of blocks is short against the launch (a block of 64 frames
-  // runs ~3 ms at 10k atoms; ~40 blocks per compute unit keep the tail below 3 %)
+  const bool fast = !literal && h->params.fast_ok != 0 &&
+                    (h->flags & MDX_RDF_TABLE_KERNEL) == 0u && h->fast_blocks > 0;
+  KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
+  if (fast) {
+    // chunks of about 10 us of work: short against the launch, long against a claim
+    int frames_per_chunk = 8;
+    if (const char *env = getenv("MDX_RDF_FRAMES_PER_CHUNK")) {
+      const int v = atoi(env);
+      if (v >= 1) frames_per_chunk = v;
+    }
+    const int64_t chunks_per_pair = ceil_div(nf, frames_per_chunk);
+    const int64_t n_chunks = chunks_per_pair * h->n_pairs_shard;
+    MDX_REQUIRE(n_chunks + h->fast_blocks < (int64_t(1) << 31), "too many work chunks");
+    MDX_TRY(h->d_counter.reserve(sizeof(unsigned int)));
+    MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int), stream));
+    const int64_t blocks = std::min<int64_t>(h->fast_blocks, n_chunks);
+    hipLaunchKernelGGL(rdf_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
+                       h->fast_lds_bytes, stream, h->d_packed.as<float>(), h->n_pad, nf,
+                       frames_per_chunk, static_cast<int>(chunks_per_pair),
+                       static_cast<int>(n_chunks), h->d_pairs_shard.as<TilePair>(),
+                       h->d_counter.as<unsigned int>(), h->params,
+                       h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
+                       h->fast_lds_hist_words, h->d_hist.as<unsigned long long>());
+    MDX_HIP(hipGetLastError());
+  }
+  // One block per (tile pair, frame group).  Frames per block: large enough to amortise
+  // the histogram flush, small enough that the last round of blocks is short against
+  // the launch.  After the fast kernel this launch only takes the frames that one left
+  // out (coordinates spread over more than 1.5 box lengths); its blocks return at once
+  // when their group has none.
   int64_t fpg = (static_cast<int64_t>(nf) * h->n_pairs_shard) / 65536;
   if (fpg < 1) fpg = 1;
   if (fpg > kMaxFramesPerGroup) fpg = kMaxFramesPerGroup;
+  if (fast) fpg = kMaxFramesPerGroup;
   if (const char *env = getenv("MDX_RDF_FRAMES_PER_GROUP")) {
     const int v = atoi(env);
     if (v >= 1 && v <= kMaxFramesPerGroup) fpg = v;
   }
   dim3 grid(static_cast<unsigned>(h->n_pairs_shard),
             static_cast<unsigned>(ceil_div(nf, fpg)));
-  KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
   if (literal) {
     hipLaunchKernelGGL(rdf_tile_kernel<true>, grid, dim3(kTile), h->lds_bytes, stream,
                        h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
                        h->d_pairs_shard.as<TilePair>(), h->params,
                        static_cast<const float *>(nullptr),
                        static_cast<const int32_t *>(nullptr), h->lds_hist_words,
-                       h->lds_thr_words, h->d_hist.as<unsigned long long>());
+                       h->lds_thr_words, h->d_hist.as<unsigned long long>(), 0);
   } else {
     hipLaunchKernelGGL(rdf_tile_kernel<false>, grid, dim3(kTile), h->lds_bytes, stream,
                        h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
                        h->d_pairs_shard.as<TilePair>(), h->params,
                        h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
                        h->lds_hist_words, h->lds_thr_words,
-                       h->d_hist.as<unsigned long long>());
+                       h->d_hist.as<unsigned long long>(), fast ? 1 : 0);
   }
   MDX_HIP(hipGetLastError());
   return MDX_OK;
@@ -752,6 +1120,13 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
           tp.tile_j = static_cast<int32_t>(tile_first[b] + tj);
           tp.key = key;
           tp.diagonal = (a == b && ti == tj) ? 1 : 0;
+          {
+            const int64_t first = strict ? 1 : 0;
+            const int64_t used = n_per_species[b] > first ? n_per_species[b] - first : 0;
+            const int64_t left = used - tj * kTile;
+            tp.j_count = static_cast<int32_t>(left < kTile ? left : kTile);
+          }
+          tp.pad_[0] = tp.pad_[1] = tp.pad_[2] = 0;
           h->pairs.push_back(tp);
         }
       }
@@ -777,6 +1152,36 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
     MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_tile_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(h->lds_bytes)));
+  }
+
+  rdf_fast_setup(p);
+  if (!literal && p.fast_ok) {
+    h->fast_lds_hist_words = (nbins + 1 + 3) & ~3;
+    h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
+                        static_cast<size_t>(kTile) * kQueueSlots + 16;
+    if (h->fast_lds_bytes <= 160 * 1024) {
+      MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_fast_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(h->fast_lds_bytes)));
+      hipFuncAttributes attr;
+      MDX_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(rdf_fast_kernel)));
+      int per_cu = 0;
+      if (attr.sharedSizeBytes == 0)  // the histogram then starts at LDS address 0
+        MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &per_cu, reinterpret_cast<const void *>(rdf_fast_kernel), kTile, h->fast_lds_bytes));
+      hipDeviceProp_t prop;
+      MDX_HIP(hipGetDeviceProperties(&prop, h->device));
+      h->fast_blocks = per_cu * prop.multiProcessorCount;
+      if (getenv("MDX_RDF_FAST_NO_EDGE")) p.fast_edge_units = 0;  // timing experiments only
+      if (getenv("MDX_RDF_DEBUG"))
+        fprintf(stderr, "rdf fast: %d blocks/CU, %d CUs, lds %zu, edge units %u of %u\n", per_cu,
+                prop.multiProcessorCount, h->fast_lds_bytes, p.fast_edge_units,
+                1u << p.fast_frac_bits);
+      if (const char *env = getenv("MDX_RDF_FAST_BLOCKS")) {
+        const int v = atoi(env);
+        if (v >= 1) h->fast_blocks = v;
+      }
+    }
   }
 
   // device tables

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (MDX_DEVICE, MDX_F32, MDX_F64, MDX_HOST, MDX_RDF_LITERAL_KERNEL,
-                   MDX_RDF_STRICT_REFERENCE_MASKS, check)
+                   MDX_RDF_STRICT_REFERENCE_MASKS, MDX_RDF_TABLE_KERNEL, check)
 
 ArrayLike = Union[np.ndarray, "DeviceArray"]
 
@@ -171,7 +171,8 @@ class RdfEngine:
     """Pair-distance histograms for one set of species on the current device."""
 
     def __init__(self, n_per_species: Sequence[int], box, cutoff, nbins: int,
-                 strict_reference_masks: bool = True, literal_kernel: bool = False):
+                 strict_reference_masks: bool = True, literal_kernel: bool = False,
+                 table_kernel: bool = False):
         self.n_per_species = [int(n) for n in n_per_species]
         self.n_species = len(self.n_per_species)
         self.n_keys = self.n_species * (self.n_species + 1) // 2
@@ -181,6 +182,8 @@ class RdfEngine:
             flags |= MDX_RDF_STRICT_REFERENCE_MASKS
         if literal_kernel:
             flags |= MDX_RDF_LITERAL_KERNEL
+        if table_kernel:
+            flags |= MDX_RDF_TABLE_KERNEL
         nps = (ctypes.c_int64 * self.n_species)(*self.n_per_species)
         box32 = np.asarray(box, dtype=np.float32)
         if box32.shape != (3,):
