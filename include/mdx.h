@@ -210,6 +210,20 @@ int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_at
                           double scalar_weight, double *out, int out_location,
                           int accumulate);
 /*
+ * mdx_weighted_atom_sum for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  x ([n_atoms][n_frames][k]) and out ([n_frames][k] float64) are device
+ * pointers, every atom has the weight scalar_weight, and the partial sums of the atom
+ * chunks live in a static 32 MiB device array of the library (one per GPU, held until
+ * the process ends) instead of an allocated block: the call makes no hipMalloc / hipFree
+ * and returns MDX_ERR_INVALID_ARGUMENT when n_frames * k exceeds 4 194 304 values.  The
+ * first call on a device looks up the array's address (and creates the library stream if
+ * no earlier call has).  Asynchronous on the library stream; every call on one GPU uses
+ * the same array, so calls that overlap on one GPU (from several host threads) race.
+ */
+int mdx_weighted_atom_sum_static(const void *x, int dtype, int64_t n_atoms, int64_t n_frames,
+                                 int k, double scalar_weight, double *out, int accumulate);
+/*
  * out[t][c] (+)= sum_a stress[a][t][3+c], c = 0..2: MomentumFlux.transform_batch
  * (mdsuite/transformations/momentum_flux.py:45-55).  stress is [n_atoms][n_frames][6].
  */

@@ -99,6 +99,10 @@ SIGNATURES = {
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                              c_f64_p, ctypes.c_double, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_int]),
+    "mdx_weighted_atom_sum_static": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                    ctypes.c_int64, ctypes.c_int,
+                                                    ctypes.c_double, ctypes.c_void_p,
+                                                    ctypes.c_int]),
     "mdx_momentum_flux": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                          ctypes.c_int, ctypes.c_int]),

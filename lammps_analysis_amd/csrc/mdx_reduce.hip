@@ -194,6 +194,33 @@ __global__ __launch_bounds__(kThreads) void combine_chunks_kernel(
   out[col] = accumulate ? (out[col] + r) : r;
 }
 
+// Partial sums of mdx_weighted_atom_sum_static: one copy of this array per GPU for the
+// life of the process (32 MiB).  In host code the name is only a handle for
+// hipGetSymbolAddress; kernels receive the address obtained there.
+constexpr int64_t kScratchDoubles = int64_t(4) << 20;
+static __device__ __align__(256) double scratch[kScratchDoubles];
+
+constexpr int kScratchDevices = 64;
+std::mutex g_scratch_mutex;
+double *g_scratch_ptr[kScratchDevices] = {nullptr};
+
+// Address of the current device's copy of `scratch` (looked up once per device).
+int scratch_address(double **ptr) {
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kScratchDevices)
+    return fail(MDX_ERR_DEVICE, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void *address = nullptr;
+    MDX_HIP(hipGetSymbolAddress(&address, HIP_SYMBOL(scratch)));
+    if (address == nullptr) return fail(MDX_ERR_DEVICE, "hipGetSymbolAddress returned null");
+    g_scratch_ptr[dev] = static_cast<double *>(address);
+  }
+  *ptr = g_scratch_ptr[dev];
+  return MDX_OK;
+}
+
 struct ChunkPlan {
   int64_t col_blocks;
   int64_t n_chunks;
@@ -321,6 +348,64 @@ int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_at
                  accumulate, stream));
   // scoped device buffers are released on return
   MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+int mdx_weighted_atom_sum_static(const void *x, int dtype, int64_t n_atoms, int64_t n_frames,
+                                 int k, double scalar_weight, double *out, int accumulate) {
+  MDX_REQUIRE(x != nullptr && out != nullptr, "null argument");
+  MDX_REQUIRE(dtype == MDX_F32 || dtype == MDX_F64, "dtype must be MDX_F32 or MDX_F64");
+  MDX_REQUIRE(n_atoms >= 0 && n_frames >= 0, "negative size");
+  MDX_REQUIRE(k >= 1 && k <= 64, "k out of range");
+  const int64_t row_len = n_frames * k;
+  MDX_REQUIRE(row_len <= kScratchDoubles,
+              "n_frames * k = %lld exceeds the %lld values the static scratch array holds; "
+              "split the frames over several calls or use mdx_weighted_atom_sum",
+              (long long)row_len, (long long)kScratchDoubles);
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  double *partial = nullptr;
+  MDX_TRY(scratch_address(&partial));
+  if (n_atoms == 0 || row_len == 0) return zero_result(out, MDX_DEVICE, row_len, accumulate, stream);
+
+  const int vec = (dtype == MDX_F32) ? 4 : 2;
+  const bool aligned = (row_len % vec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int64_t threads_needed = aligned ? row_len / vec : row_len;
+  ChunkPlan plan = plan_chunks(n_atoms, threads_needed);
+  const int64_t fit = kScratchDoubles / row_len;  // >= 1
+  if (plan.n_chunks > fit) {
+    plan.atoms_per_chunk = ceil_div(n_atoms, fit);
+    plan.n_chunks = ceil_div(n_atoms, plan.atoms_per_chunk);
+  }
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  const double *no_weights = nullptr;
+  if (dtype == MDX_F32) {
+    const float *xf = static_cast<const float *>(x);
+    if (aligned)
+      hipLaunchKernelGGL((weighted_sum_kernel<float, 4>), grid, dim3(kThreads), 0, stream, xf,
+                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial);
+    else
+      hipLaunchKernelGGL((weighted_sum_kernel<float, 1>), grid, dim3(kThreads), 0, stream, xf,
+                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial);
+  } else {
+    const double *xd = static_cast<const double *>(x);
+    if (aligned)
+      hipLaunchKernelGGL((weighted_sum_kernel<double, 2>), grid, dim3(kThreads), 0, stream, xd,
+                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial);
+    else
+      hipLaunchKernelGGL((weighted_sum_kernel<double, 1>), grid, dim3(kThreads), 0, stream, xd,
+                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
+                         partial);
+  }
+  MDX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(combine_chunks_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(row_len, kThreads))), dim3(kThreads), 0,
+                     stream, partial, static_cast<int>(plan.n_chunks), 1, row_len, out,
+                     accumulate);
+  MDX_HIP(hipGetLastError());
   return MDX_OK;
 }
 
