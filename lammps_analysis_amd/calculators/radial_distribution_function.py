@@ -265,8 +265,18 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
         total_bytes = sum(v.nbytes for v in views)
         # the upload of a whole array (53 GB/s) beats a host-side gather of the sampled frames
         # (about 1.5 GB/s through a fancy index) down to one frame in 32
-        if 32 * sample.size >= n_stored and total_bytes <= _DEVICE_RESIDENT_BYTES:
-            rdf_engine.accumulate(views, frames=sample, shard_rank=rank, shard_count=size)
+        # ... as long as the arrays fit beside the packed frames: half of the device memory
+        budget = min(_DEVICE_RESIDENT_BYTES, engine.device_info()["memory_bytes"] // 2)
+        if 32 * sample.size >= n_stored and total_bytes <= budget:
+            try:
+                rdf_engine.accumulate(views, frames=sample, shard_rank=rank, shard_count=size)
+            except MemoryError:
+                # another process holds the memory: start over with the batch loop
+                log.warning("device memory for the stored arrays is not available; "
+                            "loading frame batches instead")
+                engine.release_cached_memory()
+                rdf_engine.reset()
+                return False
             return True
         return False
 

@@ -1275,7 +1275,9 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
   // Host input with a contiguous frame range: blocks of frames are copied on a
   // second stream into two alternating staging sets while the previous block is
   // being histogrammed.
-  if (location == MDX_HOST && frames == nullptr && n_frames >= 128)
+  // A range shorter than the arrays always goes this way, whatever its length: the
+  // rows are copied frame range by frame range, never past the end of the caller's array.
+  if (location == MDX_HOST && frames == nullptr && (n_frames >= 128 || n_frames < frame_stride))
     return accumulate_host_pipelined(h, species_pos, dtype, frame_stride, n_frames, stream);
 
   // species arrays on the device

@@ -71,6 +71,11 @@ class DataManager:
                     else:
                         select_slice = np.s_[self.atom_selection, loop_array[batch]]
                 elif system:
+                    if start > 0:
+                        # the axis-0 slice of a (1, T, k) series is empty from the second
+                        # batch on (the reference would hand an empty tensor to the
+                        # calculator and fail there); batch 0 carried the whole series
+                        continue
                     select_slice = np.s_[start:stop]
                 elif isinstance(self.atom_selection, dict):
                     select_slice = {item: np.s_[sel, start:stop]

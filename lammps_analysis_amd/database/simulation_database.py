@@ -264,11 +264,14 @@ class Database:
             else:
                 my_slice = select_slice
             mm = np.load(self._file(name), mmap_mode="r")
-            try:
+            if (isinstance(my_slice, tuple) and len(my_slice) >= 2
+                    and all(isinstance(part, (list, np.ndarray)) for part in my_slice[:2])):
+                # an atom list and a frame list select a block (every listed atom at every
+                # listed frame), as h5py applies them in the reference; NumPy would pair
+                # the two lists element by element
+                arr = mm[my_slice[0]][(slice(None), my_slice[1]) + tuple(my_slice[2:])]
+            else:
                 arr = mm[my_slice]
-            except (TypeError, IndexError):
-                # two fancy indices (atom list and frame list) are applied one by one
-                arr = mm[my_slice[0]][:, my_slice[1], :]
             arr = np.asarray(arr) if dtype is None else np.asarray(arr, dtype=dtype)
             if scaling[i] != 1:
                 arr = arr * scaling[i]

@@ -432,6 +432,32 @@ def green_kubo_windowed_flux(series: np.ndarray, data_range: int, correlation_ti
     return jacf_sum, np.array(sigma)
 
 
+def green_kubo_flux_as_written(series: np.ndarray, data_range: int, correlation_time: int,
+                               time: np.ndarray, integration_range: int,
+                               batch_size: int | None = None):
+    """The ensemble loop of GreenKuboViscosity / GreenKuboThermalConductivity /
+    GreenKuboViscosityFlux exactly as the files have it
+    (calculators/green_kubo_viscosity.py:185-224): ``auto_correlation`` along AXIS 0 of
+    the ``(1, D, 3)`` window, ``jacf`` of shape ``(1, D)``, ``np.trapz(jacf[:ir],
+    x=time[:ir])`` per window (which slices the length-one axis), the sum of ``jacf`` over
+    the windows.  Returns ``(jacf_sum (1, D), sigma (n_windows, 1))``; the calculators
+    report ``prefactor * sigma[0]`` and ``prefactor * sigma[1]``.  PARITY UNPINNED (the
+    reference's tests of these calculators are disabled)."""
+    series = np.asarray(series, dtype=np.float64)
+    n_frames = series.shape[1]
+    if batch_size is None:
+        batch_size = n_frames
+    jacf_sum = np.zeros(data_range)
+    sigma = []
+    trapezoid = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
+    for origin in window_starts(batch_size, data_range, correlation_time):
+        ensemble = series[:, origin:origin + data_range]
+        jacf = data_range * np.sum(auto_correlation(ensemble, axis=0), axis=-1)
+        jacf_sum = jacf_sum + jacf
+        sigma.append(trapezoid(jacf[:integration_range], x=time[:integration_range]))
+    return jacf_sum, np.array(sigma)
+
+
 # --------------------------------------------------------- distinct diffusion
 
 def correlate(ds_a: np.ndarray, ds_b: np.ndarray) -> np.ndarray:

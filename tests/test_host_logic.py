@@ -306,3 +306,29 @@ def test_product_does_not_import_the_oracle_or_torch():
         if path.name == "parallel.py":
             text = text.replace("import torch", "")  # lazy transport import only
         assert not forbidden.search(text), path
+
+
+def test_load_data_applies_atom_and_frame_lists_as_a_block(tmp_path):
+    """An atom list and a frame list select every listed atom at every listed frame, as
+    h5py does for the reference (mdsuite/database/simulation_database.py:594-639 with the
+    loop_array slices of mdsuite/database/data_manager.py:195-203), whatever their lengths:
+    equal lengths and a single frame must not pair the two lists element by element."""
+    from lammps_analysis_amd.database.simulation_database import Database
+
+    db = Database(tmp_path / "store")
+    db.add_dataset({"Na/Positions": (6, 9, 3)})
+    full = np.arange(6 * 9 * 3, dtype=np.float32).reshape(6, 9, 3)
+    mm = np.load(db._file("Na/Positions"), mmap_mode="r+")
+    mm[:] = full
+    mm.flush()
+    for atoms, frames in (([0, 2, 5], [1, 3, 8]), ([4, 1], [7]), ([3], [0, 2, 4, 6]),
+                          (np.array([5, 0, 1, 2]), np.array([2, 3]))):
+        got = db.load_data(["Na/Positions"], select_slice=np.s_[atoms, frames])["Na/Positions"]
+        want = full[np.ix_(np.asarray(atoms), np.asarray(frames))]
+        assert got.shape == (len(atoms), len(frames), 3)
+        np.testing.assert_array_equal(got, want)
+    # slices and one list keep working
+    got = db.load_data(["Na/Positions"], select_slice=np.s_[:, [1, 4]])["Na/Positions"]
+    np.testing.assert_array_equal(got, full[:, [1, 4]])
+    got = db.load_data(["Na/Positions"], select_slice={"Na": np.s_[[0, 1], 2:5]})["Na/Positions"]
+    np.testing.assert_array_equal(got, full[[0, 1], 2:5])
