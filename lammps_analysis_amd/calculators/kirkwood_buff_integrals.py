@@ -44,19 +44,27 @@ class KirkwoodBuffIntegral(RdfConsumer):
                          number_of_bins=bins, cutoff=cutoff,
                          number_of_configurations=configurations)
 
-    def _calculate_kb_integral(self, radii_data: np.ndarray, rdf_data: np.ndarray):
-        filtered_data = apply_savgol_filter(rdf_data, order=self.args.savgol_order,
-                                            window_length=self.args.savgol_window_length)
-        integral_data = cumulative_trapezoid(
-            y=(filtered_data[1:] - 1) * (radii_data[1:]) ** 2, x=radii_data[1:])
-        return 4 * np.pi * integral_data
+    def running_integral(self, r: np.ndarray, g: np.ndarray) -> np.ndarray:
+        """``4 pi * int_0^r (g - 1) r'^2 dr'`` on the grid ``r[1:]``.
+
+        ``g`` is smoothed first (Savitzky-Golay, the two filter arguments of the call);
+        the integrand's first point is left out, so the running trapezoid sum starts at
+        ``r[1]`` and has ``len(r) - 2`` entries, as in the reference
+        (mdsuite/calculators/kirkwood_buff_integrals.py:156-178)."""
+        smooth = apply_savgol_filter(g, order=self.args.savgol_order,
+                                     window_length=self.args.savgol_window_length)
+        shell = r[1:] * r[1:]
+        return 4.0 * np.pi * cumulative_trapezoid((smooth[1:] - 1.0) * shell, x=r[1:])
 
     def run_calculator(self):
-        for selected_species, vals in self.rdf_data.data_dict.items():
-            selected_species = selected_species.split("_")
-            radii = np.array(vals["x"]).astype(float)[1:]
-            rdf = np.array(vals["y"]).astype(float)[1:]
-            kb_integral = self._calculate_kb_integral(radii_data=radii, rdf_data=rdf)
-            data = {self.result_series_keys[0]: radii[1:].tolist(),
-                    self.result_series_keys[1]: kb_integral.tolist()}
-            self.queue_data(data=data, subjects=selected_species)
+        """One integral per species pair of the RDF.  The RDF's first bin (r = 0, where
+        g is 0/0) is dropped before the filter sees it, and the integral's own first grid
+        point after that, so ``r`` in the result starts at the RDF's third bin
+        (mdsuite/calculators/kirkwood_buff_integrals.py:180-197)."""
+        r_key, g_key = self.result_series_keys
+        for pair_name, series in self.rdf_data.data_dict.items():
+            r = np.asarray(series["x"], dtype=float)[1:]
+            g = np.asarray(series["y"], dtype=float)[1:]
+            self.queue_data(data={r_key: r[1:].tolist(),
+                                  g_key: self.running_integral(r, g).tolist()},
+                            subjects=pair_name.split("_"))

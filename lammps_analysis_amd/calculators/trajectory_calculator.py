@@ -16,7 +16,8 @@ from typing import List, Union
 import numpy as np
 
 from ..database.data_manager import DataManager
-from ..database.simulation_database import Database, PropertyInfo
+from ..database.simulation_database import (Database, PropertyInfo,  # noqa: F401
+                                            open_database)
 from ..memory_management.memory_manager import MemoryManager
 from ..transformations import switcher_transformations
 from ..utils.meta_functions import join_path
@@ -75,7 +76,7 @@ class TrajectoryCalculator(Calculator, ABC):
     @property
     def database(self):
         if self._database is None:
-            self._database = Database(self.experiment.database_path / "database.hdf5")
+            self._database = open_database(self.experiment.database_path / "database.hdf5")
         return self._database
 
     # ----------------------------------------------------------- dependencies

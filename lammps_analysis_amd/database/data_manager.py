@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .simulation_database import Database
+from .simulation_database import Database, open_database  # noqa: F401
 
 
 class DataManager:
@@ -60,7 +60,7 @@ class DataManager:
                 dictionary)
 
         def generator(batch_number, batch_size, database, data_path, dictionary):
-            database = Database(database)
+            database = open_database(database)
             loop_over_remainder = self.remainder is not None and self.remainder > 0
             for batch in range(batch_number + int(loop_over_remainder)):
                 start, stop, data_size = self._frame_range(batch, batch_number, batch_size)
@@ -89,7 +89,7 @@ class DataManager:
             if isinstance(self.atom_selection, dict):
                 raise ValueError("Atom selection is not currently available "
                                  "for mini-batched calculations")
-            database = Database(database)
+            database = open_database(database)
             extra = 1 if self.atom_remainder else 0
             start = 0
             for atom_batch in range(self.n_atom_batches + extra):

@@ -317,3 +317,138 @@ class Database:
                 self._file(name).replace(self._file(new_name))
                 index[new_name] = index.pop(name)
         self._save_index(index)
+
+
+# ------------------------------------------------------------ HDF5 (optional)
+
+
+def _h5py():
+    """The h5py module, or an ImportError that says what it is needed for."""
+    try:
+        import h5py
+    except ImportError as exc:
+        raise ImportError(
+            "reading an MDSuite database.hdf5 needs the optional dependency h5py; "
+            "without it, ingest the trajectory again (Experiment.add_data), which writes "
+            "the directory-of-.npy store") from exc
+    return h5py
+
+
+class Hdf5Database(Database):
+    """Read side of a ``database.hdf5`` written by the reference.
+
+    Layout contract (mdsuite/database/simulation_database.py:449-499, 594-639 of the
+    reference): one group per species (or ``Observables``), one dataset per property,
+    shape ``[n_particles, n_configurations, n_dims]``, float32, gzip-chunked.  Slices are
+    read through h5py into contiguous float32 arrays, which the engine then uploads
+    through its page-locked staging like any other host array; an atom list combined with
+    a frame list is applied in two steps, as the reference does on h5py's ``TypeError``.
+
+    The file itself is never written.  Datasets that transformations derive
+    (``Observables/Ionic_Current`` ...) go to a directory-of-.npy store next to it
+    (``<file>.mdx``) and are found there first on later reads.
+    """
+
+    def __init__(self, path: typing.Union[str, pathlib.Path]):
+        super().__init__(path)
+        self._h5_path = pathlib.Path(path)
+        self._root = pathlib.Path(str(path) + ".mdx")
+        self._h5_shapes = None
+
+    def _h5_index(self) -> dict:
+        if self._h5_shapes is None:
+            shapes = {}
+            with _h5py().File(self._h5_path, "r") as handle:
+                def visit(name, node):
+                    if hasattr(node, "shape") and hasattr(node, "dtype"):
+                        shapes[name.strip("/")] = tuple(int(s) for s in node.shape)
+                handle.visititems(visit)
+            self._h5_shapes = shapes
+        return self._h5_shapes
+
+    def database_exists(self) -> bool:
+        return self._h5_path.is_file()
+
+    def _in_sidecar(self, name: str) -> bool:
+        return name.strip("/") in self._load_index()
+
+    def load_data(self, path_list: list = None, select_slice=np.s_[:],
+                  dictionary: bool = False, scaling: list = None, d_size: int = None,
+                  dtype=None):
+        if scaling is None:
+            scaling = [1 for _ in range(len(path_list))]
+        data = {}
+        from_file = []
+        for i, item in enumerate(path_list):
+            name = item.decode() if isinstance(item, bytes) else item
+            if self._in_sidecar(name):
+                data[item] = super().load_data([item], select_slice=select_slice,
+                                               scaling=[scaling[i]], dtype=dtype)[item]
+            else:
+                from_file.append((i, item, name))
+        if from_file:
+            with _h5py().File(self._h5_path, "r") as handle:
+                for i, item, name in from_file:
+                    if isinstance(select_slice, dict):
+                        my_slice = select_slice[name.split("/")[0]]
+                    else:
+                        my_slice = select_slice
+                    dataset = handle[name]
+                    try:
+                        arr = dataset[my_slice]
+                    except TypeError:
+                        arr = dataset[my_slice[0]][:, my_slice[1], :]
+                    arr = np.ascontiguousarray(arr, dtype=STORAGE_DTYPE if dtype is None
+                                               else dtype)
+                    if scaling[i] != 1:
+                        arr = arr * scaling[i]
+                    data[item] = arr
+        data[str.encode("data_size")] = d_size
+        return data
+
+    def check_existence(self, path: str) -> bool:
+        if super().check_existence(path):
+            return True
+        if isinstance(path, bytes):
+            path = path.decode()
+        suffix = "/" + path.strip("/")
+        return any(("/" + name).endswith(suffix) for name in self._h5_index())
+
+    def get_data_size(self, data_path: str) -> tuple:
+        if isinstance(data_path, bytes):
+            data_path = data_path.decode()
+        name = data_path.strip("/")
+        if self._in_sidecar(name):
+            return super().get_data_size(name)
+        shape = self._h5_index()[name]
+        n_bytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(STORAGE_DTYPE).itemsize
+        return shape[0], shape[1], n_bytes
+
+    def get_memory_information(self) -> dict:
+        out = {name: int(np.prod(shape, dtype=np.int64)) * 4
+               for name, shape in self._h5_index().items()}
+        out.update(super().get_memory_information())
+        return out
+
+    def get_database_summary(self):
+        groups = {name.split("/")[0] for name in self._h5_index()}
+        return sorted(groups | set(super().get_database_summary()))
+
+    def add_data(self, chunk: TrajectoryChunkData):
+        for sp_info in chunk.species_list:
+            for prop_info in sp_info.properties:
+                name = f"{sp_info.name}/{prop_info.name}"
+                if not self._in_sidecar(name) and name in self._h5_index():
+                    raise PermissionError(
+                        f"dataset '{name}' lives in {self._h5_path}, which is opened "
+                        "read-only; derived datasets go to the .mdx store beside it")
+        return super().add_data(chunk)
+
+
+def open_database(path: typing.Union[str, pathlib.Path]) -> Database:
+    """The store behind ``path``: an HDF5 file written by the reference (needs h5py) or
+    this package's directory of ``.npy`` datasets (also for a path that does not exist
+    yet)."""
+    if pathlib.Path(path).is_file():
+        return Hdf5Database(path)
+    return Database(path)

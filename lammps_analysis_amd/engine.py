@@ -20,6 +20,10 @@ ArrayLike = Union[np.ndarray, "DeviceArray"]
 
 
 def set_device(index: int) -> None:
+    from .utils.config import config
+    if config.backend != "hip":
+        raise ValueError(f"config.backend = {config.backend!r}: the only compute backend is "
+                         "'hip' (libmdx on an AMD GPU); there is no CPU path")
     check(_lib.load().mdx_set_device(int(index)))
 
 

@@ -19,7 +19,8 @@ from typing import Dict, Union
 
 import numpy as np
 
-from ..database.simulation_database import (Database, MoleculeInfo, PropertyInfo,
+from ..database.simulation_database import (Database, MoleculeInfo, PropertyInfo,  # noqa: F401
+                                            open_database,
                                             SpeciesInfo, TrajectoryMetadata)
 from ..file_io.file_read import FileProcessor
 from ..utils import units as units_module
@@ -239,7 +240,7 @@ class Experiment:
             log.info("This file has already been read, skipping this now. If this is not "
                      "desired, please add force=True to the command.")
             return
-        database = Database(self.database_path / "database.hdf5")
+        database = open_database(self.database_path / "database.hdf5")
         metadata = file_processor.metadata
         architecture = _species_list_to_architecture_dict(metadata.species_list,
                                                           metadata.n_configurations)
@@ -256,7 +257,7 @@ class Experiment:
 
     def load_matrix(self, property_name: str = None, species: typing.Iterable[str] = None,
                     select_slice=None, path: typing.Iterable[str] = None):
-        database = Database(self.database_path / "database.hdf5")
+        database = open_database(self.database_path / "database.hdf5")
         if path is not None:
             return database.load_data(path_list=path, select_slice=select_slice)
         if species is None:

@@ -242,7 +242,10 @@ def init(rank: Optional[int] = None, world_size: Optional[int] = None,
 
     n_devices = _lib.device_count()
     if n_devices > 0:
-        _state.device_index = local_rank % n_devices
+        if config.device_ids:
+            _state.device_index = int(config.device_ids[local_rank % len(config.device_ids)])
+        else:
+            _state.device_index = local_rank % n_devices
         config.device_index = _state.device_index
         _lib.check(_lib.load().mdx_set_device(_state.device_index))
     _state.channel = HostChannel(rank, world_size, address or default_address())

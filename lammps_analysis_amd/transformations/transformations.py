@@ -18,7 +18,8 @@ import numpy as np
 
 from .. import parallel
 from ..database.data_manager import DataManager
-from ..database.simulation_database import (Database, PropertyInfo, SpeciesInfo,
+from ..database.simulation_database import (Database, PropertyInfo, SpeciesInfo,  # noqa: F401
+                                            open_database,
                                             TrajectoryChunkData)
 from ..memory_management.memory_manager import MemoryManager
 from ..utils.constants import DatasetKeys
@@ -54,7 +55,7 @@ class Transformations:
     @property
     def database(self):
         if self._database is None:
-            self._database = Database(self.experiment.database_path / "database.hdf5")
+            self._database = open_database(self.experiment.database_path / "database.hdf5")
         return self._database
 
     @property

@@ -332,3 +332,104 @@ def test_load_data_applies_atom_and_frame_lists_as_a_block(tmp_path):
     np.testing.assert_array_equal(got, full[:, [1, 4]])
     got = db.load_data(["Na/Positions"], select_slice={"Na": np.s_[[0, 1], 2:5]})["Na/Positions"]
     np.testing.assert_array_equal(got, full[[0, 1], 2:5])
+
+
+class _StubH5Dataset:
+    """h5py.Dataset as far as the reader uses it: shape, dtype, and indexing that refuses
+    two index lists at once, like h5py does."""
+
+    def __init__(self, array):
+        self._array = array
+        self.shape = array.shape
+        self.dtype = array.dtype
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple) and sum(isinstance(k, (list, np.ndarray)) for k in key) > 1:
+            raise TypeError("Only one indexing vector or array is currently allowed for "
+                            "fancy indexing")
+        return self._array[key]
+
+
+class _StubH5File:
+    files = {}
+
+    def __init__(self, path, mode="r"):
+        assert mode == "r"
+        self._datasets = _StubH5File.files[str(path)]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def __getitem__(self, name):
+        return _StubH5Dataset(self._datasets[name.strip("/")])
+
+    def visititems(self, fn):
+        for group in sorted({n.split("/")[0] for n in self._datasets}):
+            fn(group, object())
+        for name, array in self._datasets.items():
+            fn(name, _StubH5Dataset(array))
+
+
+def test_hdf5_reader_with_a_stub_h5py(tmp_path, monkeypatch):
+    """The optional reader of the reference's database.hdf5 (layout [particles,
+    configurations, dims] float32, mdsuite/database/simulation_database.py:491-497,
+    594-639).  h5py is not installed here, so a stub module with its read interface stands
+    in; the file on disk only has to exist."""
+    import sys
+    import types
+    from lammps_analysis_amd.database import simulation_database as sdb
+
+    path = tmp_path / "database.hdf5"
+    path.write_bytes(b"\\x89HDF\\r\\n\\x1a\\n")
+    rng = np.random.default_rng(0)
+    stored = {"Na/Positions": rng.random((7, 20, 3)).astype(np.float32),
+              "Cl/Positions": rng.random((5, 20, 3)).astype(np.float32),
+              "Observables/Ionic_Current": rng.random((1, 20, 3)).astype(np.float32)}
+    stub = types.ModuleType("h5py")
+    stub.File = _StubH5File
+    _StubH5File.files[str(path)] = stored
+    monkeypatch.setitem(sys.modules, "h5py", stub)
+
+    db = sdb.open_database(path)
+    assert isinstance(db, sdb.Hdf5Database) and db.database_exists()
+    assert db.check_existence("Na/Positions") and db.check_existence("Ionic_Current")
+    assert not db.check_existence("Na/Velocities")
+    assert db.get_data_size("Cl/Positions") == (5, 20, 5 * 20 * 3 * 4)
+    assert db.get_database_summary() == ["Cl", "Na", "Observables"]
+    got = db.load_data([b"Na/Positions", b"Cl/Positions"], select_slice=np.s_[:, 3:9], d_size=6)
+    np.testing.assert_array_equal(got[b"Na/Positions"], stored["Na/Positions"][:, 3:9])
+    assert got[b"Na/Positions"].flags.c_contiguous and got[b"data_size"] == 6
+    # atom list + frame list: two steps, as the reference does after h5py's TypeError
+    got = db.load_data(["Na/Positions"], select_slice={"Na": np.s_[[0, 2, 5], [1, 4, 7]]})
+    np.testing.assert_array_equal(got["Na/Positions"],
+                                  stored["Na/Positions"][[0, 2, 5]][:, [1, 4, 7]])
+    # derived datasets go to the .npy store beside the file; the file stays read-only
+    db.add_dataset({"Observables/Momentum_Flux": (1, 20, 3)})
+    assert (tmp_path / "database.hdf5.mdx").is_dir()
+    chunk = sdb.TrajectoryChunkData(
+        species_list=[sdb.SpeciesInfo("Observables", 1, [sdb.PropertyInfo("Momentum_Flux", 3)])],
+        chunk_size=20)
+    flux = rng.random((20, 1, 3))
+    chunk.add_data(flux, 0, "Observables", "Momentum_Flux")
+    db.add_data(chunk)
+    back = db.load_data(["Observables/Momentum_Flux"])["Observables/Momentum_Flux"]
+    np.testing.assert_allclose(back, np.swapaxes(flux, 0, 1).astype(np.float32))
+    bad = sdb.TrajectoryChunkData(
+        species_list=[sdb.SpeciesInfo("Na", 7, [sdb.PropertyInfo("Positions", 3)])], chunk_size=2)
+    with pytest.raises(PermissionError):
+        db.add_data(bad)
+    # a directory (or nothing yet) is the native store
+    assert type(sdb.open_database(tmp_path / "store")) is sdb.Database
+
+
+def test_hdf5_reader_says_what_is_missing(tmp_path, monkeypatch):
+    import sys
+    from lammps_analysis_amd.database import simulation_database as sdb
+    path = tmp_path / "database.hdf5"
+    path.write_bytes(b"x")
+    monkeypatch.setitem(sys.modules, "h5py", None)  # import h5py -> ImportError
+    with pytest.raises(ImportError, match="h5py"):
+        sdb.open_database(path).check_existence("Na/Positions")
