@@ -35,14 +35,32 @@ ROOT = pathlib.Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-N_NA = 5000
-N_CL = 5000
-BOX = 65.0
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak
+TRAJECTORY_FRAMES = 100000       # BASELINE.json configs[1]: 10k atoms x 100k frames
+
+# workload -> species sizes, box length, cutoff, bins (cutoff = L/2 - 0.1, bins of 0.01)
+WORKLOADS = {
+    # BASELINE.json configs[1] (and [2] for the Green-Kubo side measurement)
+    "nacl": {"species": (5000, 5000), "box": 65.0,
+             "label": "10k-atom NaCl melt (5000 Na + 5000 Cl), L=65, cutoff=32.4, 3240 bins"},
+    # BASELINE.json configs[3]: atom-pair tiles of every frame sharded over the ranks
+    "water": {"species": (33334, 66666), "box": 100.0,
+              "label": "100k-atom water box (33334 O + 66666 H), L=100, cutoff=49.9, 4990 bins"},
+}
+N_NA, N_CL = WORKLOADS["nacl"]["species"]
+BOX = WORKLOADS["nacl"]["box"]
 CUTOFF = np.float32(BOX / 2 - 0.1)
 NBINS = int(CUTOFF / 0.01)
-TRAJECTORY_FRAMES = 100000       # BASELINE.json configs[1]: 10k atoms x 100k frames
-HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E spec peak
-F32_VALU_PEAK_TFLOPS = 157.3     # MI355X vector fp32 spec peak (FMA counted as 2)
+
+# Cycles one SIMD needs per wave64 instruction at the sustained rate measured by
+# scratch/valu_probe_f32.hip (profiles/r02_valu_probe.txt; 1024 SIMDs, counted at 2.4 GHz),
+# and the instructions of one loop iteration (4 pairs per lane) of the fast RDF kernel,
+# read off its ISA: 6 packed subtractions, 24 folds, 2 packed multiplies and 6 packed fma,
+# 4 square roots, 8 compares, 4 shifts and 8 masks.
+VALU_CYCLES = {"packed": 4.6, "sub_abs": 2.75, "sqrt": 8.4, "compare": 5.1, "shift": 2.3,
+               "mask": 2.4}
+FAST_LOOP_MIX = {"packed": 14, "sub_abs": 24, "sqrt": 4, "compare": 8, "shift": 4, "mask": 8}
+PAIRS_PER_LOOP_ITERATION = 4
 
 
 def parse_args():
@@ -50,52 +68,45 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="nacl",
+                    help="nacl: frames sharded over the ranks (weak scaling, the headline); "
+                         "water: every rank sees all frames and takes its share of the "
+                         "atom-pair tiles (strong scaling, configs[3])")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames per step; 0 = the configuration's 100 000 frames divided "
-                         "over the timed steps")
+                         "over the timed steps (nacl) or 16 (water)")
     ap.add_argument("--cpu-frames", type=int, default=24,
                     help="frames of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--gk-frames", type=int, default=100000,
                     help="frames of the Green-Kubo side measurement (0 disables it)")
     ap.add_argument("--skip-host-input", action="store_true",
-                    help="leave out the host-memory side measurement (counter passes: "
-                         "its 256-frame blocks share a grid with the full-size launch)")
-    ap.add_argument("--literal-kernel", action="store_true",
-                    help="time the literal-arithmetic kernel instead of the table kernel")
+                    help="leave out the host-memory side measurement")
+    ap.add_argument("--kernel", choices=("fast", "table", "literal"), default="fast",
+                    help="RDF pair kernel to time (all three give identical counts)")
     return ap.parse_args()
 
 
-def recorded_traffic(kernel_key: str):
-    """HBM-side bytes per launch of the kernel whose summary key starts with
-    ``kernel_key``, from the committed PMC summary of this command with default sizes
-    (the counters cannot be read from inside this process); None when not recorded."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
+def recorded(kernel_key: str):
+    """Per-launch counter means of a kernel from the committed PMC summary of this command
+    with default flags (profiles/r02_pmc.json; counters cannot be read from inside the
+    process); {} when not recorded."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
     try:
         with open(path) as fh:
             table = json.load(fh)
-        entries = [v for k, v in table.items() if k.startswith(kernel_key)]
-        if not entries:
-            return None
-        # several grids of one kernel: the full-size launches are the longest ones
-        entry = max(entries, key=lambda v: v["mean_duration_us_under_pmc"])
+    except (OSError, ValueError):
+        return {}
+    entries = [v for k, v in table.items() if k.startswith(kernel_key)]
+    if not entries:
+        return {}
+    # several grids of one kernel: the full-size launches are the longest ones
+    return max(entries, key=lambda v: v.get("mean_duration_us_under_pmc", 0.0))
+
+
+def traffic_of(entry: dict):
+    if "fetch_bytes_x2" in entry and "write_bytes" in entry:
         return entry["fetch_bytes_x2"] + entry["write_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def recorded_counter(kernel_key: str, counter: str):
-    """Mean of a hardware counter per launch of the longest-running grid of a kernel, from
-    the same committed summary as ``recorded_traffic``; None when not recorded."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc.json")
-    try:
-        with open(path) as fh:
-            table = json.load(fh)
-        entries = [v for k, v in table.items() if k.startswith(kernel_key) and counter in v]
-        if not entries:
-            return None
-        return max(entries, key=lambda v: v["mean_duration_us_under_pmc"])[counter]
-    except (OSError, KeyError, ValueError):
-        return None
+    return None
 
 
 def main() -> None:
@@ -131,25 +142,38 @@ def main() -> None:
         engine.synchronize()
         parallel.barrier()
 
+    work = WORKLOADS[args.workload]
+    n_per_species = list(work["species"])
+    box = work["box"]
+    cutoff = np.float32(box / 2 - 0.1)
+    nbins = int(cutoff / 0.01)
+    shard_tiles = args.workload == "water"
     steps, warmup = args.steps, args.warmup
-    fps = args.frames_per_step if args.frames_per_step > 0 else max(1, TRAJECTORY_FRAMES // steps)
+    if args.frames_per_step > 0:
+        fps = args.frames_per_step
+    else:
+        fps = 16 if shard_tiles else max(1, TRAJECTORY_FRAMES // steps)
     # the timed steps walk once through the resident trajectory (100 000 frames per rank
     # with the default step size); warm-up steps re-read its first blocks
     n_frames = fps * steps
 
     # ---- resident synthetic trajectory, reference layout [atoms][frames][3]
-    na = engine.DeviceArray((N_NA, n_frames, 3), np.float32)
-    cl = engine.DeviceArray((N_CL, n_frames, 3), np.float32)
-    na.fill_uniform(seed=1000 + 2 * rank, lo=0.0, hi=BOX)
-    cl.fill_uniform(seed=1001 + 2 * rank, lo=0.0, hi=BOX)
+    seed_shift = 0 if shard_tiles else 2 * rank  # tile shards see the same frames
+    species = []
+    for s_idx, n in enumerate(n_per_species):
+        arr = engine.DeviceArray((n, n_frames, 3), np.float32)
+        arr.fill_uniform(seed=1000 + s_idx + seed_shift, lo=0.0, hi=box)
+        species.append(arr)
 
-    rdf = engine.RdfEngine([N_NA, N_CL], [BOX, BOX, BOX], CUTOFF, NBINS,
+    rdf = engine.RdfEngine(n_per_species, [box] * 3, cutoff, nbins,
                            strict_reference_masks=True,
-                           literal_kernel=args.literal_kernel)
-    species = [na, cl]
+                           literal_kernel=args.kernel == "literal",
+                           table_kernel=args.kernel == "table")
+    shard = (rank, world) if shard_tiles else (0, 1)
 
     def step(i: int) -> None:
-        rdf.accumulate(species, frames=np.arange(i * fps, (i + 1) * fps, dtype=np.int64))
+        rdf.accumulate(species, frames=np.arange(i * fps, (i + 1) * fps, dtype=np.int64),
+                       shard_rank=shard[0], shard_count=shard[1])
 
     for i in range(warmup):
         step(i % steps)
@@ -182,63 +206,71 @@ def main() -> None:
     else:
         hist_total = rdf.read()
 
-    total_frames = steps * fps * world
+    total_frames = steps * fps * (1 if shard_tiles else world)
     value = total_frames / elapsed
     ms_per_step = elapsed / steps * 1e3
 
-    n_atoms = N_NA + N_CL
+    n_atoms = sum(n_per_species)
     pairs_per_frame = n_atoms * (n_atoms - 1) // 2
     bytes_per_frame = n_atoms * 3 * 4
     launches = max(tile_launches, 1)
     tile_avg_ms = tile_ms / launches
     frames_per_launch = steps * fps / launches
+    kernel_name = {"fast": "rdf_fast_kernel", "table": "rdf_tile_kernel<false>",
+                   "literal": "rdf_tile_kernel<true>"}[args.kernel]
+    default_run = args.workload == "nacl" and args.kernel == "fast" and args.frames_per_step == 0
+    pmc = recorded(kernel_name) if default_run else {}
     achieved_gbps = (bytes_per_frame * frames_per_launch) / (tile_avg_ms * 1e-3) / 1e9
     roofline = {
-        "kernel": "rdf_tile_kernel",
+        "kernel": kernel_name,
         "bound": "hbm",
         "achieved": achieved_gbps,
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved_gbps / HBM_PEAK_GBPS,
-        "traffic": recorded_traffic("rdf_tile_kernel<false>")
-        if (fps == 1024 and not args.literal_kernel) else None,
-        "traffic_source": "profiles/r01_pmc.json: separate rocprofv3 --pmc FETCH_SIZE and "
+        "traffic": traffic_of(pmc),
+        "traffic_source": "profiles/r02_pmc.json: separate rocprofv3 --pmc FETCH_SIZE and "
                           "WRITE_SIZE passes over this command; bytes per launch = "
                           "2*FETCH_SIZE (gfx950 counts 128-B reads as 64 B) + WRITE_SIZE",
         "avg_launch_ms": tile_avg_ms,
         "launches": tile_launches,
         "algorithmic_bytes_per_launch": bytes_per_frame * frames_per_launch,
         "note": ("BASELINE.json asks for the HBM fraction; the pair loop reuses every "
-                 "12-byte atom ~N/2 times from LDS/registers, so the physical limiter "
-                 "is f32 VALU issue + LDS atomics, see valu"),
+                 "12-byte atom ~N/2 times from registers, so the physical limiter is "
+                 "float32 vector issue, see valu"),
     }
-    pairs_per_s_kernel = pairs_per_frame * frames_per_launch / (tile_avg_ms * 1e-3)
-    # VALU issue bound of the table kernel's wrapped-frame loop: 17.5 issue slots per
-    # pair (ISA count: 1.5 packed subtract, 6 minimum image, 2.5 packed square/add,
-    # 2 for the 8-cycle v_sqrt_f32, 0.5 packed fma, 5 cutoff/bin/edge/address), one
-    # slot = 4 cycles of a SIMD16 for a 64-lane wave, 1024 SIMDs at 2.4 GHz
-    slots_per_pair = 17.5
-    issue_bound = 1024 * 2.4e9 / 4.0 * 64 / slots_per_pair
+    # float32 vector issue: cycles per pair from the fast kernel's instruction mix at the
+    # measured per-instruction rates, against the kernel time measured in this run
+    share = (1.0 / world) if shard_tiles else 1.0
+    pairs_per_s_kernel = pairs_per_frame * share * frames_per_launch / (tile_avg_ms * 1e-3)
+    cycles_per_pair = sum(VALU_CYCLES[k] * n for k, n in FAST_LOOP_MIX.items()) \
+        / PAIRS_PER_LOOP_ITERATION
+    issue_bound = 1024 * 2.4e9 * 64 / cycles_per_pair
     valu = {
         "pairs_per_s_kernel": pairs_per_s_kernel,
-        "issue_slots_per_pair": slots_per_pair,
-        "issue_bound_pairs_per_s": issue_bound,
-        "frac_of_issue_bound": pairs_per_s_kernel / issue_bound,
-        "pairs_per_s_end_to_end": pairs_per_frame * value / world,
+        "pairs_per_s_end_to_end": pairs_per_frame * value / (1 if shard_tiles else world),
         "pack_kernel_ms_total": pack_ms,
         "tile_kernel_ms_total": tile_ms,
     }
-    # measured side of the same statement: wave-level VALU instructions per launch from
-    # the SQ counter pass, 4 cycles each on one of 1024 SIMDs (v_sqrt_f32 takes 8, so
-    # the true busy fraction is higher), against the launch time measured here
-    valu_insts = recorded_counter("rdf_tile_kernel<false>", "SQ_INSTS_VALU") \
-        if (fps == 1024 and not args.literal_kernel) else None
-    if valu_insts:
-        valu["valu_insts_per_launch_pmc"] = valu_insts
-        valu["valu_insts_per_pair_slot"] = valu_insts * 64 / (pairs_per_frame * frames_per_launch)
-        valu["simd_issue_busy_frac_at_2p4GHz"] = (valu_insts * 4.0 / 1024
-                                                  / (tile_avg_ms * 1e-3 * 2.4e9))
+    if args.kernel == "fast":
+        valu.update({
+            "model": "instruction mix of the hot loop x sustained cycles per wave64 "
+                     "instruction per SIMD (profiles/r02_valu_probe.txt), 1024 SIMDs, 2.4 GHz",
+            "valu_cycles_per_pair_model": cycles_per_pair,
+            "issue_bound_pairs_per_s": issue_bound,
+            "frac_of_issue_bound": pairs_per_s_kernel / issue_bound,
+        })
+    if "SQ_INSTS_VALU" in pmc:
+        slots = pairs_per_frame * frames_per_launch / 64.0
+        valu["valu_insts_per_launch_pmc"] = pmc["SQ_INSTS_VALU"]
+        valu["valu_insts_per_wave_pair_slot_pmc"] = pmc["SQ_INSTS_VALU"] / slots
+        valu["cycles_per_wave_pair_slot_at_2p4GHz"] = (tile_avg_ms * 1e-3 * 2.4e9 * 1024) / slots
 
+    if shard_tiles:
+        parallelism = (f"atom-pair tiles of every frame dealt cyclically to {world} rank(s), "
+                       "one histogram all-reduce")
+    else:
+        parallelism = f"frames sharded over {world} rank(s), one histogram all-reduce"
     result = {
         "metric": "frames/sec (RDF + GK-ACF) on 10k-atom synthetic trajectory; %HBM-roofline",
         "value": value,
@@ -248,34 +280,42 @@ def main() -> None:
         "warmup": warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if shard_tiles else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "RadialDistributionFunction, 10k-atom NaCl melt (5000 Na + 5000 Cl), "
-                        "L=65, cutoff=32.4, 3240 bins, strict reference masks "
-                        f"(BASELINE.json configs[1]); {steps * fps} frames per rank resident "
-                        "in HBM, each histogrammed once in the timed steps",
+            "workload": f"RadialDistributionFunction, {work['label']}, strict reference masks "
+                        f"(BASELINE.json configs[{3 if shard_tiles else 1}]); "
+                        f"{steps * fps} frames per rank resident in HBM, each histogrammed "
+                        "once in the timed steps",
             "frames_per_step": fps,
             "frames_per_rank": steps * fps,
-            "parallelism": f"frames sharded over {world} rank(s), one histogram all-reduce",
-            "kernel": "literal" if args.literal_kernel else "table",
+            "parallelism": parallelism,
+            "kernel": args.kernel,
         },
         "roofline": roofline,
         "valu": valu,
         "pairs_counted": int(hist_total.sum()),
         "allreduce_ms": allreduce_ms,
+        "gk_acf_frames_per_s": None,
     }
 
     if rank == 0:
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and not shard_tiles:
             result["cpu_baseline"] = cpu_baseline(engine, species, n_frames, args.cpu_frames,
                                                   rank)
-        if args.gk_frames > 0:
+    rdf.close()
+    for arr in species:
+        arr.free()
+    if rank == 0:
+        if args.gk_frames > 0 and not shard_tiles:
             result["gk_acf"] = gk_side_measurement(engine, args.gk_frames)
-        if not args.skip_host_input:
-            result["host_input"] = host_input_measurement(engine, fps)
+            # the second half of the metric: frames/s of the GreenKuboIonicConductivity
+            # chain (configs[2]) on this GPU, measured outside the timed steps
+            result["gk_acf_frames_per_s"] = result["gk_acf"]["frames_per_s"]
+        if not args.skip_host_input and not shard_tiles:
+            result["host_input"] = host_input_measurement(engine, min(fps, 1024))
     parallel.barrier()
     transport = parallel.transport()
     parallel.shutdown()
@@ -349,8 +389,13 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
     data_range = 500
     vel_na = engine.DeviceArray((N_NA, n_frames, 3), np.float32)
     vel_cl = engine.DeviceArray((N_CL, n_frames, 3), np.float32)
-    vel_na.fill_uniform(seed=31, lo=-1.0, hi=1.0)
-    vel_cl.fill_uniform(seed=32, lo=-1.0, hi=1.0)
+    # per-atom Langevin velocities with the parameters of the reference's own test
+    # (kT = 0.7, m = 1.5, gamma = kT / 1.2345, dt = 0.1)
+    kt, mass, dt = 0.7, 1.5, 0.1
+    gamma = kt / 1.2345
+    decay, kick = 1.0 - gamma * dt / mass, np.sqrt(2.0 * kt * gamma * dt) / mass
+    vel_na.fill_langevin(seed=3, decay=decay, kick=kick)
+    vel_cl.fill_langevin(seed=4, decay=decay, kick=kick)
     tau = np.arange(data_range)
     time_axis = tau * 0.002
     n_win = n_frames - data_range
@@ -401,15 +446,16 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
     avg_ms = sum_ms / max(sum_n, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     out = {
-        "workload": f"GreenKuboIonicConductivity chain, 10k atoms x {n_frames} frames, "
-                    f"data_range {data_range}, correlation_time 1",
+        "workload": f"GreenKuboIonicConductivity chain, 10k atoms x {n_frames} frames of "
+                    f"Langevin velocities, charges +1/-1, data_range {data_range}, "
+                    "correlation_time 1 (BASELINE.json configs[2])",
         "frames_per_s": n_frames / dt,
         "ms_per_pass": dt * 1e3,
         "ms_per_pass_series_via_host": dt_host * 1e3,
         "roofline_atom_sum": {
             "kernel": "weighted_sum_kernel<float,4>", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": recorded_traffic("weighted_sum_kernel<float, 4>")
+            "traffic": traffic_of(recorded("weighted_sum_kernel<float, 4>"))
             if n_frames == 100000 else None,
             "avg_launch_ms": avg_ms, "launches": sum_n,
             "algorithmic_bytes_per_launch": bytes_per_launch},

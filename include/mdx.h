@@ -101,6 +101,15 @@ int mdx_profile_query(int slot, double *total_ms, int64_t *launches);
  * element i gets lo + (hi-lo)*u(seed, i), u = 24-bit counter hash in [0,1). */
 int mdx_fill_uniform_f32(float *dptr, uint64_t n, uint64_t seed, float lo, float hi);
 
+/* Fill a device array [n_atoms][n_frames][k] with synthetic Langevin velocities (bench
+ * only): every (atom, component) is an independent Ornstein-Uhlenbeck series
+ * v[t+1] = decay * v[t] + kick * xi with standard normal xi, started from its stationary
+ * distribution; the discretisation of the reference's own Langevin test
+ * (CI/integration_tests/calculators/test_green_kubo_self_diffusion_coefficients.py:53-73:
+ * decay = 1 - gamma dt / m, kick = sqrt(2 kT gamma dt) / m). */
+int mdx_fill_ou_f32(float *dptr, int64_t n_atoms, int64_t n_frames, int k, uint64_t seed,
+                    float decay, float kick);
+
 /* ---------------------------------------------------------------------- RDF */
 /*
  * Replaces the per-batch body of RadialDistributionFunction.run_calculator

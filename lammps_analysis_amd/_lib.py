@@ -75,6 +75,9 @@ SIGNATURES = {
     "mdx_fill_uniform_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64,
                                             ctypes.c_uint64, ctypes.c_float,
                                             ctypes.c_float]),
+    "mdx_fill_ou_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int, ctypes.c_uint64, ctypes.c_float,
+                                       ctypes.c_float]),
     "mdx_rdf_create": (ctypes.c_int, [c_void_pp, ctypes.c_int, c_i64_p, c_f32_p,
                                       ctypes.c_float, ctypes.c_int, ctypes.c_uint32]),
     "mdx_rdf_destroy": (ctypes.c_int, [ctypes.c_void_p]),

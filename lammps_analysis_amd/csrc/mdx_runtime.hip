@@ -477,3 +477,44 @@ extern "C" int mdx_fill_uniform_f32(float *dptr, uint64_t n, uint64_t seed, floa
   MDX_HIP(hipGetLastError());
   return MDX_OK;
 }
+
+// Ornstein-Uhlenbeck (Langevin) velocities, one independent series per (atom, component):
+//   v[t+1] = decay * v[t] + kick * xi,  xi standard normal (Box-Muller on the counter
+// hash above), v[0] drawn from the stationary distribution kick / sqrt(1 - decay^2).
+// Thread = one series, walking the frame axis of the [atoms][frames][k] array.
+__global__ __launch_bounds__(256) void mdx_fill_ou_kernel(float *out, int64_t n_series_atoms,
+                                                          int64_t n_frames, int k,
+                                                          uint64_t seed, float decay,
+                                                          float kick) {
+  const int64_t series = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (series >= n_series_atoms * k) return;
+  const int64_t atom = series / k;
+  const int c = static_cast<int>(series - atom * k);
+  float *p = out + (atom * n_frames) * k + c;
+  const uint64_t base = static_cast<uint64_t>(series) * static_cast<uint64_t>(n_frames + 1) * 2u;
+  const float stationary = kick * rsqrtf(fmaxf(1.0f - decay * decay, 1e-12f));
+  float v = 0.0f;
+  for (int64_t t = -1; t < n_frames - 1; ++t) {
+    const uint64_t i = base + static_cast<uint64_t>(t + 1) * 2u;
+    const float u1 = fmaxf(mdx_hash_unit(seed, i), 5.9604645e-8f);
+    const float u2 = mdx_hash_unit(seed, i + 1);
+    const float xi = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+    v = (t < 0) ? stationary * xi : decay * v + kick * xi;
+    p[(t + 1) * k] = v;
+  }
+}
+
+extern "C" int mdx_fill_ou_f32(float *dptr, int64_t n_atoms, int64_t n_frames, int k,
+                               uint64_t seed, float decay, float kick) {
+  MDX_REQUIRE(dptr != nullptr, "null pointer");
+  MDX_REQUIRE(n_atoms >= 0 && n_frames >= 0 && k >= 1, "bad size");
+  MDX_REQUIRE(decay >= 0.0f && decay < 1.0f, "decay must lie in [0, 1)");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  const int64_t n = n_atoms * k;
+  if (n == 0 || n_frames == 0) return MDX_OK;
+  hipLaunchKernelGGL(mdx_fill_ou_kernel, dim3(static_cast<unsigned>(ceil_div(n, 256))),
+                     dim3(256), 0, s, dptr, n_atoms, n_frames, k, seed, decay, kick);
+  MDX_HIP(hipGetLastError());
+  return MDX_OK;
+}

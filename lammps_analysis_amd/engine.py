@@ -86,6 +86,14 @@ class DeviceArray:
         n = self.nbytes // 4
         check(_lib.load().mdx_fill_uniform_f32(self.ptr, n, int(seed), float(lo), float(hi)))
 
+    def fill_langevin(self, seed: int, decay: float, kick: float) -> None:
+        """Synthetic Ornstein-Uhlenbeck velocities along axis 1 of an ``[atoms, frames,
+        k]`` float32 array; see mdx_fill_ou_f32."""
+        if self.dtype != np.float32 or len(self.shape) != 3:
+            raise TypeError("fill_langevin needs a float32 array of shape (atoms, frames, k)")
+        check(_lib.load().mdx_fill_ou_f32(self.ptr, self.shape[0], self.shape[1],
+                                          self.shape[2], int(seed), float(decay), float(kick)))
+
     def reshape(self, shape) -> "DeviceArray":
         """The same memory under another shape; the result does not own it and keeps
         this array alive."""
