@@ -67,7 +67,10 @@ struct TilePair {
   int32_t key;
   int32_t diagonal;  // 1: same tile on both sides, only j > i counts
   int32_t j_count;   // atoms in the j tile (the rest of its 256 slots is padding)
-  int32_t pad_[3];   // 32 bytes: an entry is fetched with two 16-byte scalar loads
+  // position of the pair's key in the (sharded) pair list, which is sorted by key
+  int32_t key_first_pair;
+  int32_t key_pairs;
+  int32_t pad_;      // 32 bytes: an entry is fetched with two 16-byte scalar loads
 };
 
 struct RdfParams {
@@ -499,18 +502,25 @@ __device__ __forceinline__ void fast_tile_loop(
                      g_thr, p);
 }
 
-// Persistent blocks with a shared work counter.  A chunk is up to frames_per_chunk
-// consecutive frames of one tile pair, numbered pair * chunks_per_pair + group with the
-// tile pairs in key order.  Every block claims the next chunk with one global atomic
-// until none is left, so the blocks drain the launch together whatever their pace, and
-// since they all move through the keys in step a block flushes its LDS histogram only
-// a few times per launch (on a key change and at the end).  Frames that are not
-// "wrapped" are skipped (the table kernel takes them).
+// Persistent blocks with shared work counters.  A chunk is up to frames_per_chunk
+// consecutive frames (a frame group) of one tile pair.  The frame groups are dealt to
+// eight lists by group % 8, one list per XCD label (blockIdx % 8 tells which blocks share
+// an XCD and with it an L2): a block first drains its own label's list, so a frame's
+// positions are pulled into one L2 only, then helps the other labels out.  Within a list
+// chunks are numbered key by key (the tile pairs are sorted by key), within a key frame
+// group by frame group, within a group pair by pair: the blocks of a label work on the
+// same few frames at any time (their j-tiles come from that L2), and since they move
+// through the keys in step a block flushes its LDS histogram only a few times per launch
+// (on a key change and at the end).  Every block claims chunks with one global atomic
+// each until all eight lists are empty, so the launch drains evenly whatever the blocks'
+// pace.  Frames that are not "wrapped" are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
+constexpr int kWorkLists = 8;
+
 __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
-    int chunks_per_pair, int n_chunks, const TilePair *__restrict__ pairs,
-    unsigned int *__restrict__ work_counter, RdfParams p, const float *__restrict__ g_thr,
+    int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
+    unsigned int *__restrict__ work_counters, RdfParams p, const float *__restrict__ g_thr,
     const int32_t *__restrict__ frame_wrapped, int lds_hist_words,
     unsigned long long *__restrict__ g_hist) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -530,48 +540,62 @@ __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
   const uint32_t one = in_vgpr(1u);
 
   int cur_key = -1;
-  for (;;) {
-    if (tid == 0) *claim = atomicAdd(work_counter, 1u);
-    __syncthreads();
-    const uint32_t chunk = *claim;
-    __syncthreads();  // everyone has read the claim before thread 0 writes the next
-    if (chunk >= static_cast<uint32_t>(n_chunks)) break;
-    const int pair_index = static_cast<int>(chunk / static_cast<uint32_t>(chunks_per_pair));
-    const int group = static_cast<int>(chunk - pair_index * static_cast<uint32_t>(chunks_per_pair));
-    const TilePair tp = pairs[pair_index];
-    if (tp.key != cur_key) {
-      if (cur_key >= 0) {
-        unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
-        for (int b = tid; b < p.nbins; b += kTile) {
-          const uint32_t v = hist[b];
-          if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
-        }
-        __syncthreads();
-      }
-      for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
+  for (int turn = 0; turn < kWorkLists; ++turn) {
+    const int list = (static_cast<int>(blockIdx.x) + turn) % kWorkLists;
+    // frame groups list, list + 8, ...: how many, and the list's chunk count
+    const uint32_t list_groups =
+        n_groups > list ? static_cast<uint32_t>((n_groups - list + kWorkLists - 1) / kWorkLists) : 0u;
+    const uint32_t list_chunks = list_groups * static_cast<uint32_t>(n_pairs);
+    if (list_chunks == 0u) continue;
+    for (;;) {
+      if (tid == 0) *claim = atomicAdd(&work_counters[list], 1u);
       __syncthreads();
-      cur_key = tp.key;
+      const uint32_t chunk = *claim;
+      __syncthreads();  // everyone has read the claim before thread 0 writes the next
+      if (chunk >= list_chunks) break;
+      // chunk / list_groups lies inside the key's range of pairs: that finds the key
+      const TilePair in_key = pairs[chunk / list_groups];
+      const uint32_t local = chunk - static_cast<uint32_t>(in_key.key_first_pair) * list_groups;
+      const uint32_t turn_in_list = local / static_cast<uint32_t>(in_key.key_pairs);
+      const int pair_index =
+          in_key.key_first_pair +
+          static_cast<int>(local - turn_in_list * static_cast<uint32_t>(in_key.key_pairs));
+      const int group = list + kWorkLists * static_cast<int>(turn_in_list);
+      const TilePair tp = pairs[pair_index];
+      if (tp.key != cur_key) {
+        if (cur_key >= 0) {
+          unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
+          for (int b = tid; b < p.nbins; b += kTile) {
+            const uint32_t v = hist[b];
+            if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
+          }
+          __syncthreads();
+        }
+        for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
+        __syncthreads();
+        cur_key = tp.key;
+      }
+      const int f_begin = group * frames_per_chunk;
+      const int f_end = min(n_frames, f_begin + frames_per_chunk);
+      const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
+      for (int f = f_begin; f < f_end; ++f) {
+        if (frame_wrapped[f] == 0) continue;
+        const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
+        const float xi = X[slot_i];
+        const float yi = X[n_pad + slot_i];
+        const float zi = X[2 * n_pad + slot_i];
+        const float *xj = X + static_cast<int64_t>(tp.tile_j) * kTile;
+        const float *yj = xj + n_pad;
+        const float *zj = yj + n_pad;
+        if (tp.diagonal)
+          fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+        else
+          fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+                                hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+      }
+      __syncthreads();  // the chunk's counts are in before a flush or the next claim
     }
-    const int f_begin = group * frames_per_chunk;
-    const int f_end = min(n_frames, f_begin + frames_per_chunk);
-    const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
-    for (int f = f_begin; f < f_end; ++f) {
-      if (frame_wrapped[f] == 0) continue;
-      const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
-      const float xi = X[slot_i];
-      const float yi = X[n_pad + slot_i];
-      const float zi = X[2 * n_pad + slot_i];
-      const float *xj = X + static_cast<int64_t>(tp.tile_j) * kTile;
-      const float *yj = xj + n_pad;
-      const float *zj = yj + n_pad;
-      if (tp.diagonal)
-        fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid, hx,
-                             hy, hz, scale, magic, addr_mask, frac_mask, one);
-      else
-        fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid, hx,
-                              hy, hz, scale, magic, addr_mask, frac_mask, one);
-    }
-    __syncthreads();  // the chunk's counts are in before a flush or the next claim
   }
   if (cur_key >= 0) {
     unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
@@ -817,6 +841,15 @@ int upload_shard(mdx_rdf_s *h, int rank, int count, hipStream_t stream) {
   for (size_t t = 0; t < h->pairs.size(); ++t) {
     if (static_cast<int64_t>(t) % count == rank) mine.push_back(h->pairs[t]);
   }
+  for (size_t first = 0; first < mine.size();) {
+    size_t last = first;
+    while (last < mine.size() && mine[last].key == mine[first].key) ++last;
+    for (size_t t = first; t < last; ++t) {
+      mine[t].key_first_pair = static_cast<int32_t>(first);
+      mine[t].key_pairs = static_cast<int32_t>(last - first);
+    }
+    first = last;
+  }
   MDX_HIP(hipStreamSynchronize(stream));
   MDX_TRY(h->d_pairs_shard.alloc(mine.size() * sizeof(TilePair) + 16));
   if (!mine.empty()) {
@@ -874,16 +907,16 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
       const int v = atoi(env);
       if (v >= 1) frames_per_chunk = v;
     }
-    const int64_t chunks_per_pair = ceil_div(nf, frames_per_chunk);
-    const int64_t n_chunks = chunks_per_pair * h->n_pairs_shard;
+    const int64_t n_groups = ceil_div(nf, frames_per_chunk);
+    const int64_t n_chunks = n_groups * h->n_pairs_shard;
     MDX_REQUIRE(n_chunks + h->fast_blocks < (int64_t(1) << 31), "too many work chunks");
-    MDX_TRY(h->d_counter.reserve(sizeof(unsigned int)));
-    MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int), stream));
-    const int64_t blocks = std::min<int64_t>(h->fast_blocks, n_chunks);
+    MDX_TRY(h->d_counter.reserve(sizeof(unsigned int) * kWorkLists));
+    MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int) * kWorkLists, stream));
+    const int64_t blocks = std::min<int64_t>(h->fast_blocks, std::max<int64_t>(n_chunks, kWorkLists));
     hipLaunchKernelGGL(rdf_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
                        h->fast_lds_bytes, stream, h->d_packed.as<float>(), h->n_pad, nf,
-                       frames_per_chunk, static_cast<int>(chunks_per_pair),
-                       static_cast<int>(n_chunks), h->d_pairs_shard.as<TilePair>(),
+                       frames_per_chunk, static_cast<int>(n_groups),
+                       static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),
                        h->d_counter.as<unsigned int>(), h->params,
                        h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
                        h->fast_lds_hist_words, h->d_hist.as<unsigned long long>());
@@ -1126,7 +1159,9 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
             const int64_t left = used - tj * kTile;
             tp.j_count = static_cast<int32_t>(left < kTile ? left : kTile);
           }
-          tp.pad_[0] = tp.pad_[1] = tp.pad_[2] = 0;
+          tp.key_first_pair = 0;
+          tp.key_pairs = 1;
+          tp.pad_ = 0;
           h->pairs.push_back(tp);
         }
       }
@@ -1313,7 +1348,7 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
 
   // frames are processed in chunks bounded by the packed image size
   const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
-  int64_t chunk = static_cast<int64_t>((size_t(1) << 30) / bytes_per_frame);
+  int64_t chunk = static_cast<int64_t>((size_t(2) << 30) / bytes_per_frame);
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 32768) chunk = 32768;
