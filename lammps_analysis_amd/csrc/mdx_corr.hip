@@ -756,6 +756,31 @@ __global__ __launch_bounds__(kWaves * 64) void acf_strip_kernel(
 // 8-frame lane stride over all LDS banks.
 // K = number of components when known at compile time (the next series is then
 // fetched into registers while the current one is being processed), 0 otherwise.
+// Block index -> (frame tile, lag tile, series chunk) of the band kernels.  The grid is
+// one-dimensional and a multiple of eight.  Blocks with equal blockIdx.x % 8 share an XCD
+// and its L2: each such group takes a contiguous eighth of the items in the order
+// (chunk, frame tile, lag tile), so the blocks running on an XCD at any time stage
+// neighbouring frame tiles of the same series and find most of their frames in that L2
+// (a frame is staged by up to six frame tiles and every lag tile).  Returns false for the
+// padding blocks of the last eighth.
+__device__ __forceinline__ bool band_item(int64_t tiles_t, int tiles_m, int n_chunks,
+                                          int64_t *tile_t_index, int *tile_m_index, int *chunk) {
+  const int64_t n_items = tiles_t * tiles_m * n_chunks;
+  const int64_t per_group = (n_items + 7) / 8;
+  const int64_t within = blockIdx.x / 8;
+  const int64_t item = static_cast<int64_t>(blockIdx.x % 8) * per_group + within;
+  if (within >= per_group || item >= n_items) return false;
+  *tile_m_index = static_cast<int>(item % tiles_m);
+  const int64_t rest = item / tiles_m;
+  *tile_t_index = rest % tiles_t;
+  *chunk = static_cast<int>(rest / tiles_t);
+  return true;
+}
+
+inline unsigned band_grid(int64_t tiles_t, int64_t tiles_m, int64_t n_chunks) {
+  return static_cast<unsigned>(8 * ceil_div(tiles_t * tiles_m * n_chunks, 8));
+}
+
 template <int MG>
 struct BandTile {
   static constexpr int TG = kThreads / MG;
@@ -773,16 +798,20 @@ struct BandTile {
 template <typename T, int K, int MG, bool kMsd>
 __global__ __launch_bounds__(kThreads) void acf_band_kernel(
     const T *__restrict__ x, int64_t n_series, int64_t n_frames, int k_runtime, int64_t t0,
-    int64_t t_len, int R, int64_t series_per_chunk, double *__restrict__ Q) {
+    int64_t t_len, int R, int64_t series_per_chunk, double *__restrict__ Q, int64_t tiles_t,
+    int tiles_m, int n_chunks) {
   using Tile = BandTile<MG>;
+  int64_t block_t;
+  int block_m, block_chunk;
+  if (!band_item(tiles_t, tiles_m, n_chunks, &block_t, &block_m, &block_chunk)) return;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   double *img = reinterpret_cast<double *>(lds_raw);  // [2][k][pitch]
   const int k = (K > 0) ? K : k_runtime;
   const int mg = threadIdx.x % MG;
   const int tg = threadIdx.x / MG;
-  const int64_t tile_t = static_cast<int64_t>(blockIdx.x) * Tile::T;
-  const int tile_m = blockIdx.y * Tile::M;
-  const int64_t s0 = static_cast<int64_t>(blockIdx.z) * series_per_chunk;
+  const int64_t tile_t = block_t * Tile::T;
+  const int tile_m = block_m * Tile::M;
+  const int64_t s0 = static_cast<int64_t>(block_chunk) * series_per_chunk;
   const int64_t s1 = min(n_series, s0 + series_per_chunk);
   // staged per series: the tile's frames x[t] first, then the T + M frames x[t + m]
   // starting at frame0
@@ -865,7 +894,7 @@ __global__ __launch_bounds__(kThreads) void acf_band_kernel(
     buf ^= 1;  // the other image was last read before this iteration's barrier
   }
   if (!kMsd) {
-    double *out = Q + static_cast<int64_t>(blockIdx.z) * t_len * R;
+    double *out = Q + static_cast<int64_t>(block_chunk) * t_len * R;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int64_t t = tile_t + 8 * tg + i;
@@ -890,7 +919,7 @@ __global__ __launch_bounds__(kThreads) void acf_band_kernel(
     red[tg * Tile::M + 8 * mg + j] = sum;
   }
   __syncthreads();
-  double *out = Q + (static_cast<int64_t>(blockIdx.z) * gridDim.x + blockIdx.x) * R;
+  double *out = Q + (static_cast<int64_t>(block_chunk) * tiles_t + block_t) * R;
   for (int m = threadIdx.x; m < Tile::M; m += kThreads) {
     if (tile_m + m >= R) continue;
     double sum = 0.0;
@@ -924,15 +953,19 @@ constexpr int kMfPitch = kMfFrames + 16;
 template <typename T>
 __global__ __launch_bounds__(kThreads) void acf_band_mfma_kernel(
     const T *__restrict__ x, int64_t n_series, int64_t n_frames, int64_t t0, int64_t t_len,
-    int R, int64_t series_per_chunk, double *__restrict__ Q) {
+    int R, int64_t series_per_chunk, double *__restrict__ Q, int64_t tiles_t, int tiles_m,
+    int n_chunks) {
+  int64_t block_t;
+  int block_m, block_chunk;
+  if (!band_item(tiles_t, tiles_m, n_chunks, &block_t, &block_m, &block_chunk)) return;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   // staged in the input type (converted when read): [2][kMfRows][kMfPitch]
   T(*img)[kMfRows][kMfPitch] = reinterpret_cast<T(*)[kMfRows][kMfPitch]>(lds_raw);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t tile_t = static_cast<int64_t>(blockIdx.x) * kMfT;
-  const int tile_m = blockIdx.y * kMfM;
-  const int64_t s0 = static_cast<int64_t>(blockIdx.z) * series_per_chunk;
+  const int64_t tile_t = block_t * kMfT;
+  const int tile_m = block_m * kMfM;
+  const int64_t s0 = static_cast<int64_t>(block_chunk) * series_per_chunk;
   const int64_t s1 = min(n_series, s0 + series_per_chunk);
 
   // staging: thread = (series slots wave, wave + 4, frames lane + 64 q)
@@ -987,7 +1020,7 @@ __global__ __launch_bounds__(kThreads) void acf_band_mfma_kernel(
     }
     buf ^= 1;  // the other image was last read before this round's barrier
   }
-  double *out = Q + static_cast<int64_t>(blockIdx.z) * t_len * R;
+  double *out = Q + static_cast<int64_t>(block_chunk) * t_len * R;
 #pragma unroll
   for (int j = 0; j < kMfTiles; ++j) {
 #pragma unroll
@@ -1231,10 +1264,10 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
       if (band) {
         using Tile = BandTile<32>;
         const size_t lds_q = Tile::lds_bytes(k);
-        dim3 grid_q(static_cast<unsigned>(ceil_div(t_len, Tile::T)),
-                    static_cast<unsigned>(ceil_div(R, Tile::M)), static_cast<unsigned>(n_chunks));
-        dim3 grid_mf(static_cast<unsigned>(ceil_div(t_len, kMfT)),
-                     static_cast<unsigned>(ceil_div(R, kMfM)), static_cast<unsigned>(n_chunks));
+        const int64_t q_tiles_t = ceil_div(t_len, Tile::T), q_tiles_m = ceil_div(R, Tile::M);
+        const int64_t mf_tiles_t = ceil_div(t_len, kMfT), mf_tiles_m = ceil_div(R, kMfM);
+        dim3 grid_q(band_grid(q_tiles_t, q_tiles_m, n_chunks));
+        dim3 grid_mf(band_grid(mf_tiles_t, mf_tiles_m, n_chunks));
         KernelTimer timer(MDX_SLOT_ACF_PARTIAL, stream);
 #define MDX_LAUNCH_BAND(TYPE, KK)                                                            \
   do {                                                                                       \
@@ -1243,7 +1276,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_q)));               \
     hipLaunchKernelGGL((acf_band_kernel<TYPE, KK, 32, false>), grid_q, dim3(kThreads), lds_q, \
                        stream, static_cast<const TYPE *>(dx), n_series, n_frames, k, t0,     \
-                       t_len, R, series_per_chunk, d_C.as<double>());                        \
+                       t_len, R, series_per_chunk, d_C.as<double>(), q_tiles_t,              \
+                       static_cast<int>(q_tiles_m), static_cast<int>(n_chunks));             \
   } while (0)
 #define MDX_LAUNCH_BAND_MFMA(TYPE)                                                           \
   do {                                                                                       \
@@ -1253,7 +1287,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
                                 static_cast<int>(lds_mf)));                                  \
     hipLaunchKernelGGL((acf_band_mfma_kernel<TYPE>), grid_mf, dim3(kThreads), lds_mf,        \
                        stream, static_cast<const TYPE *>(dx), n_series, n_frames, t0, t_len, \
-                       R, series_per_chunk, d_C.as<double>());                               \
+                       R, series_per_chunk, d_C.as<double>(), mf_tiles_t,                    \
+                       static_cast<int>(mf_tiles_m), static_cast<int>(n_chunks));            \
   } while (0)
         const bool mfma = (k == 3) && getenv("MDX_ACF_BAND_VALU") == nullptr;
         if (dtype == MDX_F32) {
@@ -1695,8 +1730,7 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
     const int64_t n_blocks = tiles_t * n_chunks;
     MDX_TRY(d_partial.alloc(sizeof(double) * n_blocks * R));
     MDX_TRY(d_out.alloc(sizeof(double) * R));
-    dim3 grid_q(static_cast<unsigned>(tiles_t), static_cast<unsigned>(tiles_m),
-                static_cast<unsigned>(n_chunks));
+    dim3 grid_q(band_grid(tiles_t, tiles_m, n_chunks));
     {
       KernelTimer timer(MDX_SLOT_MSD, stream);
 #define MDX_LAUNCH_MSD_BAND(TYPE, KK, MGG)                                                   \
@@ -1706,7 +1740,8 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_q)));               \
     hipLaunchKernelGGL((acf_band_kernel<TYPE, KK, MGG, true>), grid_q, dim3(kThreads), lds_q, \
                        stream, static_cast<const TYPE *>(dx), n_series, n_frames, k,         \
-                       win_begin, n_win, R, series_per_chunk, d_partial.as<double>());       \
+                       win_begin, n_win, R, series_per_chunk, d_partial.as<double>(),        \
+                       tiles_t, static_cast<int>(tiles_m), static_cast<int>(n_chunks));      \
   } while (0)
 #define MDX_LAUNCH_MSD_BAND_K(TYPE, MGG)                                                     \
   do {                                                                                       \
