@@ -79,7 +79,12 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
         """Same arguments as the reference (:139-213).  Engine-only keyword:
         ``strict_reference_masks`` (default ``config.strict_reference_masks`` = True)
         reproduces the reference's strict species masks, which leave the first atom of
-        every species out of all pairs (:637-638); ``False`` counts every atom."""
+        every species out of all pairs (:637-638); ``False`` counts every atom.
+        ``shard`` says how several ranks (one per GPU) split the work: ``"tiles"`` -- every
+        rank loads all sampled frames and evaluates its share of the atom-pair tiles;
+        ``"frames"`` -- every rank loads and evaluates its share of the frames; ``"auto"``
+        (default) -- tiles when there are at least eight tile pairs per rank, else
+        frames.  The counts are the same either way."""
         self.args = Args(number_of_bins=number_of_bins, cutoff=cutoff, start=start,
                          stop=stop, atom_selection=atom_selection, data_range=1,
                          correlation_time=1, molecules=molecules, species=species,
@@ -91,6 +96,9 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
         self.tqdm_limit = kwargs.pop("tqdm", 10)
         self.strict_reference_masks = kwargs.pop("strict_reference_masks",
                                                  config.strict_reference_masks)
+        self.shard = kwargs.pop("shard", "auto")
+        if self.shard not in ("auto", "tiles", "frames"):
+            raise ValueError("shard must be 'auto', 'tiles' or 'frames'")
 
     # ------------------------------------------------------------------ set-up
 
@@ -293,13 +301,26 @@ class RadialDistributionFunction(TrajectoryCalculator, ABC):
         rdf_engine = engine.RdfEngine(particles, box, np.float32(self.args.cutoff),
                                       self.args.number_of_bins,
                                       strict_reference_masks=self.strict_reference_masks)
-        if not self._accumulate_from_the_store(rdf_engine, rank, size):
+        by_frames = size > 1 and (self.shard == "frames" or (
+            self.shard == "auto" and rdf_engine.num_tiles < 8 * size))
+        if by_frames:
+            # this rank's frames, all tile pairs; the prefactor keeps the total count
+            self.sample_configurations = parallel.split_frames(
+                np.asarray(self.sample_configurations), rank, size)
+            split_arr = [part for part in np.array_split(self.sample_configurations,
+                                                         len(split_arr)) if len(part)]
+            self.override_n_batches = max(1, len(split_arr))  # the loader re-plans its batches
+            rank, size = 0, 1
+        if len(self.sample_configurations) == 0:
+            pass  # more ranks than frames: nothing to add on this one
+        elif not self._accumulate_from_the_store(rdf_engine, rank, size):
             batch_ds = self.get_batch_dataset(subject_list=self.args.species,
                                               loop_array=split_arr, correct=True)
             for batch in batch_ds:
                 positions = [np.ascontiguousarray(batch[key], dtype=np.float32)
                              for key in dict_keys]
-                # every rank sees the same frames and evaluates its share of pair tiles
+                # tile sharding: every rank sees the same frames and evaluates its share
+                # of the pair tiles
                 rdf_engine.accumulate(positions, shard_rank=rank, shard_count=size)
         histograms = parallel.reduce_histograms(rdf_engine)  # the one exchange step
         rdf_engine.close()

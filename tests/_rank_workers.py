@@ -213,6 +213,10 @@ def gpu_calculators(rank, world, workdir):
         data.add_data(vel[k], 0, k, "Velocities")
     exp.add_data(ScriptInput(data=data, metadata=metadata, name="test_name"))
     rdf = exp.run.RadialDistributionFunction(number_of_configurations=200, plot=False)
+    rdf_tiles = exp.run.RadialDistributionFunction(number_of_configurations=150, plot=False,
+                                                   shard="tiles")
+    rdf_frames = exp.run.RadialDistributionFunction(number_of_configurations=151, plot=False,
+                                                    shard="frames")
     gk = exp.run.GreenKuboIonicConductivity(plot=False, data_range=120, correlation_time=1)
     vacf = exp.run.GreenKuboDiffusionCoefficients(plot=False, data_range=60,
                                                   correlation_time=1)
@@ -220,6 +224,8 @@ def gpu_calculators(rank, world, workdir):
     out = {
         "transport": parallel.transport(),
         "rdf": {k: np.array(v["y"][1:]) for k, v in rdf.data_dict.items()},
+        "rdf_tiles": {k: np.array(v["y"][1:]) for k, v in rdf_tiles.data_dict.items()},
+        "rdf_frames": {k: np.array(v["y"][1:]) for k, v in rdf_frames.data_dict.items()},
         "gk_acf": np.array(gk["System"]["acf"]),
         "gk_sigma": gk["System"]["ionic_conductivity"],
         "gk_unc": gk["System"]["uncertainty"],

@@ -32,8 +32,9 @@ def test_two_ranks_on_one_gpu_match_one_rank(gpu, tmp_path):
     for rank, res in two:
         assert res["transport"] == "host"
         assert set(res["rdf"]) == set(one["rdf"]) == {"Na_Na", "Na_Cl", "Cl_Cl"}
-        for key in one["rdf"]:
-            np.testing.assert_array_equal(res["rdf"][key], one["rdf"][key])
+        for name in ("rdf", "rdf_tiles", "rdf_frames"):  # auto, tile shards, frame shards
+            for key in one[name]:
+                np.testing.assert_array_equal(res[name][key], one[name][key])
         _close(res["gk_acf"], one["gk_acf"])
         _close(res["gk_sigma"], one["gk_sigma"], 1e-10)
         _close(res["gk_unc"], one["gk_unc"], 1e-9)
