@@ -268,13 +268,29 @@ def init(rank: Optional[int] = None, world_size: Optional[int] = None,
     if rank == 0:
         _lib.check(lib.mdx_comm_unique_id(uid, _lib.MDX_COMM_ID_BYTES))
     uid_bytes = _state.channel.bcast(uid.raw if rank == 0 else None)
+    # The communicator is created on a helper thread: if a peer never shows up (or the
+    # node's fabric is misconfigured) ncclCommInitRank blocks for good, and a calculator
+    # run should then go on with host sums rather than hang.
     handle = ctypes.c_void_p()
-    rc = lib.mdx_comm_create(ctypes.byref(handle), rank, world_size, uid_bytes,
-                             _lib.MDX_COMM_ID_BYTES)
-    error = None if rc == 0 else lib.mdx_last_error().decode("utf-8", "replace")
+    outcome = {}
+
+    def create():
+        lib.mdx_set_device(_state.device_index)  # the current device is a per-thread setting
+        rc_ = lib.mdx_comm_create(ctypes.byref(handle), rank, world_size, uid_bytes,
+                                  _lib.MDX_COMM_ID_BYTES)
+        outcome["rc"] = rc_
+        outcome["error"] = None if rc_ == 0 else lib.mdx_last_error().decode("utf-8", "replace")
+
+    import threading
+    worker = threading.Thread(target=create, name="mdx-comm-create", daemon=True)
+    worker.start()
+    worker.join(float(os.environ.get("MDX_COMM_INIT_TIMEOUT", "120")))
+    timed_out = worker.is_alive()
+    rc = outcome.get("rc", -1)
+    error = "ncclCommInitRank did not return in time" if timed_out else outcome.get("error")
     errors = _state.channel.allgather(error)
     if any(e is not None for e in errors):
-        if rc == 0:
+        if rc == 0 and not timed_out:
             lib.mdx_comm_destroy(handle)
         if transport == "rccl":
             raise RuntimeError(f"RCCL communicator could not be created: {errors}")
