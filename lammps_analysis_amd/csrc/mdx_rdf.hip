@@ -168,8 +168,10 @@ __device__ __forceinline__ void pair_literal(float xi, float yi, float zi, float
   }
 }
 
-// Flags the frames whose coordinate differences all stay below t_far, so that
-// the minimum-image shift is at most one box length ("wrapped" frames).
+// Classifies every frame by the spread of its coordinates: 2 = "compact", every
+// coordinate difference is at most one box length (what a trajectory wrapped into the box
+// gives; the fast kernel's error bound assumes it); 1 = "wrapped", the differences stay
+// below t_far, so the minimum-image shift is at most one box length; 0 = neither.
 // One block per frame; NaN padding is ignored by fminf/fmaxf.
 __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict__ packed,
                                                          int64_t n_pad, RdfParams p,
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict
   const int f = blockIdx.x;
   const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
   const float inf = __builtin_inff();
-  bool ok = true;
+  bool ok = true, compact = true;
   for (int c = 0; c < 3; ++c) {
     float mn = inf, mx = -inf;
     for (int64_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
@@ -204,11 +206,13 @@ __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict
         mn = fminf(mn, s_min[c][w]);
         mx = fmaxf(mx, s_max[c][w]);
       }
-      // no atom at all: mx - mn = -inf - inf = -inf, counts as wrapped
+      // no atom at all: mx - mn = -inf - inf = -inf, counts as compact.  The rounded
+      // difference of the extremes bounds every rounded difference (rounding is monotone).
       const float extent = mx - mn;
       ok = ok && (extent < p.t_far[c]) && (p.t_far[c] > 0.0f);
+      compact = compact && (extent <= p.box[c]);
     }
-    wrapped[f] = ok ? 1 : 0;
+    wrapped[f] = ok ? (compact ? 2 : 1) : 0;
   }
 }
 
@@ -331,7 +335,7 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
 // ----------------------------------------------------------------- fast kernel
 
 // Bits of the float that holds the approximate bin position of one pair, for frames
-// whose coordinate differences stay below t_far ("wrapped" frames).
+// whose coordinate differences are at most one box length ("compact" frames).
 //   r = x_j - x_i (the literal difference), then per component
 //   m = h - ||r| - h|,  h = box / 2      (= min(|r|, box - |r|) up to two roundings)
 //   s = fma(mz, mz, fma(my, my, mx * mx)),  root = v_sqrt_f32(s)       (1 ulp)
@@ -513,7 +517,7 @@ __device__ __forceinline__ void fast_tile_loop(
 // through the keys in step a block flushes its LDS histogram only a few times per launch
 // (on a key change and at the end).  Every block claims chunks with one global atomic
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
-// pace.  Frames that are not "wrapped" are skipped (the table kernel takes them).
+// pace.  Frames that are not "compact" are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
       const int f_end = min(n_frames, f_begin + frames_per_chunk);
       const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
       for (int f = f_begin; f < f_end; ++f) {
-        if (frame_wrapped[f] == 0) continue;
+        if (frame_wrapped[f] != 2) continue;  // compact frames only, see rdf_fast_setup
         const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
         const float xi = X[slot_i];
         const float yi = X[n_pad + slot_i];
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
   if (!kLiteral && only_unwrapped) {
     // complement of the fast kernel: most launches have nothing to do here
     bool any = false;
-    for (int f = f_begin; f < f_end; ++f) any = any || (frame_wrapped[f] == 0);
+    for (int f = f_begin; f < f_end; ++f) any = any || (frame_wrapped[f] != 2);
     if (!any) return;
   }
 
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
       const float *yj = xj + n_pad;
       const float *zj = yj + n_pad;
       const bool wrapped = frame_wrapped[f] != 0;
-      if (wrapped && only_unwrapped) continue;
+      if (only_unwrapped && frame_wrapped[f] == 2) continue;  // the fast kernel took it
       if (tp.diagonal) {
         if (wrapped)
           table_tile_loop<true, true>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
@@ -755,16 +759,21 @@ inline float first_a_reaching(float target, float box) {
 
 // Parameters of the fast kernel and the bound that makes it exact.
 //
-// For a pair in a wrapped frame (|r_c| < t_far_c, about 1.5 box lengths) let pos_lit =
+// For a pair in a compact frame (|r_c| <= L_c in every component) let pos_lit =
 // double(d_lit) / step be the position the literal sequence bins, and P the number the
-// fast loop forms before adding 2^k + shift (fast_position_bits).  With u = 2^-24:
-//   * per component |m - m_lit| <= 2 u L_c: t = |r| - h rounds by at most u |t| < u L_c,
-//     m = h - |t| by at most u h = u L_c / 2, the literal L_c - |r| by at most u L_c / 2,
-//     and h - ||r| - h| = min(|r|, L_c - |r|) exactly (h = L_c / 2 is exact);
-//     hence the two exact norms differ by at most A = 2 u |L|;
-//   * both squared sums carry three roundings (relative 3 u), a square root halves that,
-//     v_sqrt_f32 is good to one ulp (2 u), the literal sqrtf to u / ... ; the scale
-//     nbins / cutoff is rounded once: |P - pos_lit| <= A / step + 9 u pos;
+// fast loop forms before adding 2^k + shift (fast_position_bits).  With u = 2^-24 and
+// h = L_c / 2 (exact):
+//   * per component |m - m_lit| <= u L_c.  h - ||r| - h| equals min(|r|, L_c - |r|) in
+//     exact arithmetic.  Of the fast path's two subtractions at most one rounds: for
+//     |r| < h/2, t = |r| - h rounds (by at most u |t| <= u h) and then h/2 < |t| <= h
+//     makes m = h - |t| exact; for h/2 <= |r| <= 2h, t is exact (both operands within a
+//     factor two) and m rounds by at most u |m| <= u h.  The literal value is |r| itself
+//     or L_c - |r| rounded by at most u h.  Hence the two exact norms differ by at most
+//     A = u |L|;
+//   * the fast squared sum carries three roundings, (1 + u)^3, so its root 1.5 u, and
+//     v_sqrt_f32 is good to one ulp (2 u); the literal squared sum likewise 1.5 u after
+//     the root and sqrtf adds u; the scale nbins / cutoff is rounded once (u):
+//     |P - pos_lit| <= A / step + 7.1 u pos (7 u and the second-order terms);
 //   * the addition rounds to the grid 2^-F: at most 2^-(F+1) more.
 // delta is the sum for pos <= nbins + 2 (plus 1e-6 for the top edge, which the literal
 // rule places at double(cutoff) / step rather than at nbins).  With shift >= delta the
@@ -787,7 +796,7 @@ void rdf_fast_setup(RdfParams &p) {
                                   static_cast<double>(p.box[1]) * p.box[1] +
                                   static_cast<double>(p.box[2]) * p.box[2]);
   const double grid = std::ldexp(1.0, -frac_bits);
-  const double delta = 2.0 * u * norm_l / p.step + 9.0 * u * (p.nbins + 2.0) + 0.5 * grid + 1e-6;
+  const double delta = u * norm_l / p.step + 7.1 * u * (p.nbins + 2.0) + 0.5 * grid + 1e-6;
   const double units = std::ceil(delta / grid);
   if (2.0 * units > 0.125 / grid) return;  // more than one pair in eight would be resolved
   const uint32_t shift_units = static_cast<uint32_t>(units);

@@ -48,8 +48,8 @@ def test_rdf_nacl_melt_at_size_against_the_c_oracle(gpu):
     assert ref.sum() > 4e7
 
 
-@pytest.mark.parametrize("case", ["rectangular", "outside_box", "lattice_on_edges",
-                                  "many_bins", "few_bins", "clustered"])
+@pytest.mark.parametrize("case", ["rectangular", "outside_box", "slightly_outside",
+                                  "lattice_on_edges", "many_bins", "few_bins", "clustered"])
 def test_rdf_kernels_agree_where_the_fast_one_could_slip(gpu, case):
     """The fast kernel bins an approximation and repairs the pairs near a bin edge.  Cases
     that stress that: a rectangular box, coordinates several boxes away (frames it must
@@ -67,6 +67,11 @@ def test_rdf_kernels_agree_where_the_fast_one_could_slip(gpu, case):
     if case == "outside_box":
         pos[0][:, 1] += np.float32(3.0) * box          # whole frame shifted by 3 boxes
         pos[1][::7, 2] -= np.float32(2.0) * box        # a few atoms two boxes away
+    elif case == "slightly_outside":
+        # a few atoms a little past the faces: spread between 1 and 1.5 box lengths, the
+        # class of frames that only the table kernel may take
+        pos[0][::11, 0] += np.float32(0.3) * box
+        pos[1][::5, 2] -= np.float32(0.2) * box
     elif case == "lattice_on_edges":
         grid = np.stack(np.meshgrid(*[np.arange(8)] * 3, indexing="ij"), -1).reshape(-1, 3)
         box = np.array([8.0, 8.0, 8.0], dtype=np.float32)
