@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import pathlib
 import sys
@@ -517,9 +518,15 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "frames_per_s": n_frames / dt_m,
         "ms_per_pass": dt_m * 1e3,
         "band_kernel_ms": msd_avg,
-        # subtract + fma per origin, lag, atom and component
+        "kernel": "msd_band_mfma_kernel<float, 112>",
+        # algorithmic count: subtract, multiply, add per origin, lag, atom and component
         "band_kernel_tflops_f64": (3.0 * n_frames * msd_range * N_NA * 3
                                    / (msd_avg * 1e-3) / 1e12) if msd_avg else None,
+        # what the matrix cores execute: 64-frame tiles x 128 columns (112 lags + the half
+        # tiles at both ends), 2 flops per element, row and component
+        "mfma_tflops_issued": (2.0 * 64 * math.ceil(n_frames / 64) * 128 * N_NA * 3
+                               / (msd_avg * 1e-3) / 1e12) if msd_avg else None,
+        "mfma_f64_sustained_tflops": 47.0,
     }
     vel_na.free()
     vel_cl.free()

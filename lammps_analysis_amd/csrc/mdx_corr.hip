@@ -1034,6 +1034,165 @@ __global__ __launch_bounds__(kThreads) void acf_band_mfma_kernel(
   }
 }
 
+// Mean-square displacement of three-component series on the matrix cores:
+//   partial[chunk * tiles_t + tile][m] = sum_{t in tile, t < t_len} sum_s |x_s[t + m] - x_s[t]|^2
+// through |b - a|^2 = |a|^2 + |b|^2 - 2 a.b, the cross term being the band of the Gram matrix
+// that acf_band_mfma_kernel forms (same tiles, staging and operand layout, lag tile kM).
+// The expansion cancels, so every series is first referred to its position at the
+// tile's first frame: the staged values are then displacements over at most
+// 128 + kM frames, of the size of the result itself, and the three terms lose a few of
+// float64's sixteen digits instead of the square of (position / displacement).  The
+// reference of each staged row sits beside the image and is subtracted, in float64,
+// when an operand is read; the squares |x - ref|^2 are summed per frame by the staging
+// threads.  Lag 0 is written as the exact zero it is.
+template <int kM>
+struct MsdMf {
+  static constexpr int kT = 64;
+  static constexpr int kTiles = kM / 16 + 1;
+  static constexpr int kFrames = kT + (kT + kM);
+  static constexpr int kPerLane = (kFrames + 63) / 64;  // staging slots per lane and row
+  static constexpr int kPitch = 64 * kPerLane + 16;      // rows 16 banks apart
+  static constexpr size_t kRefBytes = sizeof(double) * 2 * kMfRows;
+  static size_t lds_bytes(size_t elem) {
+    const size_t image = kRefBytes + elem * 2 * kMfRows * kPitch;
+    const size_t finish = sizeof(double) * (4 * kFrames + kFrames + 16 * kM);
+    return image > finish ? image : finish;
+  }
+};
+
+template <typename T, int kM>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 8 && kM == 256) ? 1 : 2)))
+void msd_band_mfma_kernel(
+    const T *__restrict__ x, int64_t n_series, int64_t n_frames, int64_t t0, int64_t t_len,
+    int R, int64_t series_per_chunk, double *__restrict__ partial, int64_t tiles_t,
+    int tiles_m, int n_chunks) {
+  using C = MsdMf<kM>;
+  int64_t block_t;
+  int block_m, block_chunk;
+  if (!band_item(tiles_t, tiles_m, n_chunks, &block_t, &block_m, &block_chunk)) return;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double(*refs)[kMfRows] = reinterpret_cast<double(*)[kMfRows]>(lds_raw);
+  T(*img)[kMfRows][C::kPitch] =
+      reinterpret_cast<T(*)[kMfRows][C::kPitch]>(lds_raw + C::kRefBytes);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t tile_t = block_t * C::kT;
+  const int tile_m = block_m * kM;
+  const int64_t s0 = static_cast<int64_t>(block_chunk) * series_per_chunk;
+  const int64_t s1 = min(n_series, s0 + series_per_chunk);
+
+  constexpr int kSlots = kMfSeries / 4;
+  int64_t own_frame[C::kPerLane];
+#pragma unroll
+  for (int q = 0; q < C::kPerLane; ++q) {
+    const int f = lane + 64 * q;
+    const int64_t frame =
+        (f < C::kT) ? (t0 + tile_t + f) : (t0 + tile_t + tile_m + (f - C::kT));
+    own_frame[q] = (f < C::kFrames && frame < n_frames) ? frame : -1;
+  }
+  T pre[kSlots][C::kPerLane][3];
+  auto fetch = [&](int64_t s_base) {
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) {
+      const int64_t s = s_base + wave + 4 * u;
+      const T *series = x + s * n_frames * 3;
+#pragma unroll
+      for (int q = 0; q < C::kPerLane; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          pre[u][q][d] = (s < s1 && own_frame[q] >= 0) ? series[own_frame[q] * 3 + d] : T(0);
+    }
+  };
+
+  v4d acc[C::kTiles];
+#pragma unroll
+  for (int j = 0; j < C::kTiles; ++j) acc[j] = v4d{0.0, 0.0, 0.0, 0.0};
+  double sq[C::kPerLane];
+#pragma unroll
+  for (int q = 0; q < C::kPerLane; ++q) sq[q] = 0.0;
+
+  if (s0 < s1) fetch(s0);
+  int buf = 0;
+  const int kk = lane >> 4;
+  const int col = lane & 15;
+  for (int64_t s_base = s0; s_base < s1; s_base += kMfSeries) {
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        // lane 0 holds the tile's first frame of this wave's series
+        const double ref = static_cast<double>(__shfl(pre[u][0][d], 0));
+        if (lane == 0) refs[buf][(wave + 4 * u) * 3 + d] = ref;
+#pragma unroll
+        for (int q = 0; q < C::kPerLane; ++q) {
+          img[buf][(wave + 4 * u) * 3 + d][lane + 64 * q] = pre[u][q][d];
+          const double diff = static_cast<double>(pre[u][q][d]) - ref;
+          sq[q] = fma(diff, diff, sq[q]);
+        }
+      }
+    __syncthreads();
+    if (s_base + kMfSeries < s1) fetch(s_base + kMfSeries);
+#pragma unroll
+    for (int g = 0; g < kMfRows / 4; ++g) {
+      const T *row = img[buf][4 * g + kk];
+      const double ref = refs[buf][4 * g + kk];
+      const double a = static_cast<double>(row[16 * wave + col]) - ref;
+#pragma unroll
+      for (int j = 0; j < C::kTiles; ++j) {
+        const double b = static_cast<double>(row[C::kT + 16 * (wave + j) + col]) - ref;
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+      }
+    }
+    buf ^= 1;  // the other image was last read before this round's barrier
+  }
+
+  // per staged frame: squares summed over the four waves' series
+  __syncthreads();  // the images are no longer read
+  double *sqs = reinterpret_cast<double *>(lds_raw);  // [4][kFrames]
+  double *ssum = sqs + 4 * C::kFrames;                // [kFrames]
+  double *strip = ssum + C::kFrames;                  // [4 waves x 4 rows][kM]
+#pragma unroll
+  for (int q = 0; q < C::kPerLane; ++q)
+    if (lane + 64 * q < C::kFrames) sqs[wave * C::kFrames + lane + 64 * q] = sq[q];
+  __syncthreads();
+  for (int f = threadIdx.x; f < C::kFrames; f += kThreads)
+    ssum[f] = ((sqs[f] + sqs[C::kFrames + f]) + sqs[2 * C::kFrames + f]) + sqs[3 * C::kFrames + f];
+  // cross terms: lag m collects the diagonal D[t][t + m] of every wave's strip, four
+  // rows per wave at a time, in a fixed order
+  double cross = 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    __syncthreads();  // ssum written / the previous rows consumed
+    const int trow = kk + 4 * r;
+#pragma unroll
+    for (int j = 0; j < C::kTiles; ++j) {
+      const int m_rel = 16 * j + col - trow;
+      if (m_rel >= 0 && m_rel < kM) strip[(wave * 4 + kk) * kM + m_rel] = acc[j][r];
+    }
+    __syncthreads();
+    if (threadIdx.x < kM) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+          if (tile_t + 16 * w + k4 + 4 * r < t_len)
+            cross = cross + strip[(w * 4 + k4) * kM + threadIdx.x];
+    }
+  }
+  const int m = tile_m + static_cast<int>(threadIdx.x);
+  if (threadIdx.x < kM && m < R) {
+    double own = 0.0, shifted = 0.0;
+    for (int t = 0; t < C::kT; ++t)
+      if (tile_t + t < t_len) {
+        own = own + ssum[t];
+        shifted = shifted + ssum[C::kT + t + threadIdx.x];
+      }
+    const double value = (own + shifted) - 2.0 * cross;
+    partial[(static_cast<int64_t>(block_chunk) * tiles_t + block_t) * R + m] =
+        (m == 0) ? 0.0 : value;
+  }
+}
+
 // ------------------------------------------------------------------------ MSD
 
 // partial[block][i] = sum over the block's windows and series of
@@ -1715,16 +1874,27 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
   // squared displacements of a tile of origins x lags from one staged image per series.
   if (ti.identity && correlation_time == 1 && n_series >= 8 && R >= 16) {
     const bool narrow = R <= 128;
-    const int tile_t = narrow ? BandTile<16>::T : BandTile<32>::T;
-    const int tile_m = narrow ? BandTile<16>::M : BandTile<32>::M;
-    const size_t lds_q = narrow ? BandTile<16>::lds_bytes(k) : BandTile<32>::lds_bytes(k);
+    // three components go to the matrix cores unless MDX_MSD_BAND_VALU is set; their
+    // lag tile is 112 (covers the default data_range of 100 with 8 tiles of 16), 128 or 256
+    const bool mfma = (k == 3) && getenv("MDX_MSD_BAND_VALU") == nullptr;
+    const int mfma_m = R <= 112 ? 112 : (R <= 128 ? 128 : 256);
+    const int tile_t = mfma ? 64 : (narrow ? BandTile<16>::T : BandTile<32>::T);
+    const int tile_m = mfma ? mfma_m : (narrow ? BandTile<16>::M : BandTile<32>::M);
+    const size_t elem = dtype_size(dtype);
+    const size_t lds_q =
+        mfma ? (mfma_m == 112 ? MsdMf<112>::lds_bytes(elem)
+                              : (mfma_m == 128 ? MsdMf<128>::lds_bytes(elem)
+                                               : MsdMf<256>::lds_bytes(elem)))
+             : (narrow ? BandTile<16>::lds_bytes(k) : BandTile<32>::lds_bytes(k));
     const int64_t tiles_t = ceil_div(n_win, tile_t);
     const int64_t tiles_m = ceil_div(R, tile_m);
-    int64_t n_chunks = ceil_div(2048, tiles_t * tiles_m);
+    // enough blocks that the last, partly filled round of resident blocks is a small share
+    int64_t n_chunks = ceil_div(mfma ? 16384 : 2048, tiles_t * tiles_m);
     if (n_chunks > n_series / 8) n_chunks = n_series / 8;
     if (n_chunks > 65535) n_chunks = 65535;
     if (n_chunks < 1) n_chunks = 1;
-    const int64_t series_per_chunk = ceil_div(n_series, n_chunks);
+    int64_t series_per_chunk = ceil_div(n_series, n_chunks);
+    if (mfma) series_per_chunk = 8 * ceil_div(series_per_chunk, 8);  // whole staging rounds
     n_chunks = ceil_div(n_series, series_per_chunk);
     MDX_REQUIRE(tiles_t <= 2147483647LL, "grid too large");
     const int64_t n_blocks = tiles_t * n_chunks;
@@ -1747,11 +1917,32 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
   do {                                                                                       \
     if (k == 3) MDX_LAUNCH_MSD_BAND(TYPE, 3, MGG); else MDX_LAUNCH_MSD_BAND(TYPE, 0, MGG);   \
   } while (0)
-      if (dtype == MDX_F32) {
+#define MDX_LAUNCH_MSD_MFMA(TYPE, MM)                                                         \
+  do {                                                                                       \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(msd_band_mfma_kernel<TYPE, MM>),                      \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_q)));               \
+    hipLaunchKernelGGL((msd_band_mfma_kernel<TYPE, MM>), grid_q, dim3(kThreads), lds_q,      \
+                       stream, static_cast<const TYPE *>(dx), n_series, n_frames, win_begin, \
+                       n_win, R, series_per_chunk, d_partial.as<double>(), tiles_t,          \
+                       static_cast<int>(tiles_m), static_cast<int>(n_chunks));               \
+  } while (0)
+      if (mfma) {
+        if (dtype == MDX_F32) {
+          if (mfma_m == 112) MDX_LAUNCH_MSD_MFMA(float, 112);
+          else if (mfma_m == 128) MDX_LAUNCH_MSD_MFMA(float, 128);
+          else MDX_LAUNCH_MSD_MFMA(float, 256);
+        } else {
+          if (mfma_m == 112) MDX_LAUNCH_MSD_MFMA(double, 112);
+          else if (mfma_m == 128) MDX_LAUNCH_MSD_MFMA(double, 128);
+          else MDX_LAUNCH_MSD_MFMA(double, 256);
+        }
+      } else if (dtype == MDX_F32) {
         if (narrow) MDX_LAUNCH_MSD_BAND_K(float, 16); else MDX_LAUNCH_MSD_BAND_K(float, 32);
       } else {
         if (narrow) MDX_LAUNCH_MSD_BAND_K(double, 16); else MDX_LAUNCH_MSD_BAND_K(double, 32);
       }
+#undef MDX_LAUNCH_MSD_MFMA
 #undef MDX_LAUNCH_MSD_BAND_K
 #undef MDX_LAUNCH_MSD_BAND
     }

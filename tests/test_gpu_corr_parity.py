@@ -296,3 +296,19 @@ def test_msd_band_path_many_series(gpu, S, T, D, k, begin, dtype):
     assert_close(got, c_oracle.msd_windows(pos.astype(np.float64), 1, begin, end, tau,
                                            scale=0.25), rtol=1e-10)
     assert got[0] == 0.0
+
+
+@pytest.mark.parametrize("dtype,offset", [(np.float32, 1.0e3), (np.float64, 1.0e6)])
+@pytest.mark.parametrize("D", [100, 120, 300])
+def test_msd_three_components_small_lags_far_from_origin(gpu, dtype, offset, D):
+    """Three-component series take the matrix-core kernel, which expands the squared
+    difference.  Slow walkers far from the origin (|x|^2 / msd(1) = 1e9 ... 1e15) must
+    keep every lag to 1e-9 of its own value, not only of the largest lag."""
+    rng = np.random.default_rng(23)
+    S, T = 40, 1500
+    pos = (np.cumsum(0.01 * rng.normal(size=(S, T, 3)), axis=1) + offset).astype(dtype)
+    tau = np.arange(D)
+    got = gpu.msd_windows(pos, 1, 3, T - D, tau)
+    ref = c_oracle.msd_windows(pos.astype(np.float64), 1, 3, T - D, tau)
+    assert got[0] == 0.0 and ref[0] == 0.0
+    np.testing.assert_allclose(got[1:], ref[1:], rtol=1e-9, atol=0.0)
