@@ -258,6 +258,22 @@ int mdx_energy_weighted_sum(const void *x, const void *ke, const void *pe, int d
                             int location, int64_t n_atoms, int64_t n_frames, double *out,
                             int out_location, int accumulate);
 
+/*
+ * out[t][:] (+)= sum_a pos[a][t][:] * (I_a(t) + pe[a][t]) with the running integral
+ * I_a(t) = carry[a] + dt * sum_{u <= t} force[a][u] . vel[a][u], one species and one batch
+ * of KinaciIntegratedHeatCurrent.transform_batch (mdsuite/transformations/
+ * kinaci_integrated_heat_current.py:53-87; dt = time_step * sample_rate, the cumulative
+ * sum including frame t as tf.cumsum does).  carry ([n_atoms], host) holds I_a at the last
+ * frame of the previous batch: read when have_carry != 0, always written with I_a at this
+ * batch's last frame.  pos are the unwrapped positions; pe is [n_atoms][n_frames][1].
+ * The integral belongs to an atom; the reference text sums the integrals of all species
+ * element by element (which only runs for species of equal size), this entry point does not.
+ */
+int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
+                            const void *pe, int dtype, int location, int64_t n_atoms,
+                            int64_t n_frames, double dt, int have_carry, double *carry,
+                            double *out, int out_location, int accumulate);
+
 /* ------------------------------------------- angular distribution function */
 /*
  * Weighted angle histograms of all atom triples, one batch of configurations of

@@ -117,6 +117,11 @@ SIGNATURES = {
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                                ctypes.c_int]),
+    "mdx_kinaci_heat_current": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_double,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_int]),
     "mdx_adf_num_combinations": (ctypes.c_int, [ctypes.c_int]),
     "mdx_adf_accumulate": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_i64_p, ctypes.c_int64,

@@ -5,6 +5,7 @@ from .einstein_diffusion_coefficients import EinsteinDiffusionCoefficients
 from .einstein_distinct_diffusion_coefficients import EinsteinDistinctDiffusionCoefficients
 from .einstein_helfand_ionic_conductivity import EinsteinHelfandIonicConductivity
 from .einstein_helfand_thermal_conductivity import EinsteinHelfandThermalConductivity
+from .einstein_helfand_thermal_kinaci import EinsteinHelfandThermalKinaci
 from .green_kubo_distinct_diffusion_coefficients import \
     GreenKuboDistinctDiffusionCoefficients
 from .green_kubo_ionic_conductivity import GreenKuboIonicConductivity
@@ -19,7 +20,7 @@ from .radial_distribution_function import RadialDistributionFunction
 __all__ = ["AngularDistributionFunction", "CoordinationNumbers", "KirkwoodBuffIntegral",
            "PotentialOfMeanForce", "EinsteinDiffusionCoefficients", "EinsteinDistinctDiffusionCoefficients",
            "GreenKuboDistinctDiffusionCoefficients", "EinsteinHelfandIonicConductivity",
-           "EinsteinHelfandThermalConductivity",
+           "EinsteinHelfandThermalConductivity", "EinsteinHelfandThermalKinaci",
            "GreenKuboIonicConductivity", "GreenKuboDiffusionCoefficients",
            "GreenKuboThermalConductivity", "GreenKuboViscosity", "GreenKuboViscosityFlux",
            "RadialDistributionFunction"]

@@ -177,6 +177,112 @@ __global__ __launch_bounds__(kThreads) void energy_weighted_kernel(
   for (int i = 0; i < 3; ++i) dst[t * 3 + i] = acc[i];
 }
 
+// ---- Kinaci integrated heat current: a running time integral per atom in front of
+// the atom reduction.  Thread = frame, block = 256 consecutive frames, grid.y = atom
+// chunks.  The power force.velocity of four atoms at a time is scanned over the block's
+// frames (wave shuffles, then the four waves' totals through LDS); a first launch
+// leaves every block's total per atom, a per-atom pass turns those into the integral
+// at each block's first frame, and a second launch of the same scan adds that offset
+// and reduces position * (integral + potential energy) over the chunk's atoms.
+constexpr int kScanAtoms = 4;
+
+__device__ __forceinline__ void block_inclusive_scan(double (&v)[kScanAtoms],
+                                                     double (*wave_tot)[kScanAtoms]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+    for (int u = 0; u < kScanAtoms; ++u) {
+      const double below = __shfl_up(v[u], off);
+      if (lane >= off) v[u] = v[u] + below;
+    }
+  __syncthreads();  // the totals of the previous four atoms have been read
+  if (lane == 63)
+#pragma unroll
+    for (int u = 0; u < kScanAtoms; ++u) wave_tot[wave][u] = v[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kScanAtoms; ++u) {
+    double before = 0.0;
+    for (int w = 0; w < wave; ++w) before = before + wave_tot[w][u];
+    v[u] = v[u] + before;
+  }
+}
+
+// kReduce == false: totals[block][atom] = sum over the block's frames of force.vel
+// kReduce == true:  partial[chunk][t*3+c] = sum_a pos[a][t][c] * (carry[a] + dt *
+//                   (totals[block][a] + scan) + pe[a][t]), totals holding the sums of
+//                   the blocks before this one
+template <typename T, bool kReduce>
+__global__ __launch_bounds__(kThreads) void kinaci_kernel(
+    const T *__restrict__ pos, const T *__restrict__ vel, const T *__restrict__ force,
+    const T *__restrict__ pe, int64_t n_atoms, int64_t n_frames, int64_t atoms_per_chunk,
+    double dt, const double *__restrict__ carry, double *__restrict__ totals,
+    double *__restrict__ partial) {
+  __shared__ double wave_tot[kThreads / 64][kScanAtoms];
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const bool live = t < n_frames;
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int64_t a = a0; a < a1; a += kScanAtoms) {
+    double power[kScanAtoms];
+#pragma unroll
+    for (int u = 0; u < kScanAtoms; ++u) {
+      power[u] = 0.0;
+      if (live && a + u < a1) {
+        const int64_t at = ((a + u) * n_frames + t) * 3;
+        double sum = static_cast<double>(force[at]) * static_cast<double>(vel[at]);
+        sum = sum + static_cast<double>(force[at + 1]) * static_cast<double>(vel[at + 1]);
+        sum = sum + static_cast<double>(force[at + 2]) * static_cast<double>(vel[at + 2]);
+        power[u] = sum;
+      }
+    }
+    block_inclusive_scan(power, wave_tot);
+    if (!kReduce) {
+      if (threadIdx.x == kThreads - 1)
+#pragma unroll
+        for (int u = 0; u < kScanAtoms; ++u)
+          if (a + u < a1) totals[static_cast<int64_t>(blockIdx.x) * n_atoms + a + u] = power[u];
+      continue;
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int u = 0; u < kScanAtoms; ++u) {
+      if (a + u >= a1) continue;
+      const int64_t at = (a + u) * n_frames + t;
+      const double before = totals[static_cast<int64_t>(blockIdx.x) * n_atoms + a + u];
+      const double integral = carry[a + u] + (before + power[u]) * dt;
+      const double e = integral + static_cast<double>(pe[at]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[i] = acc[i] + static_cast<double>(pos[at * 3 + i]) * e;
+    }
+  }
+  if (kReduce && live) {
+    double *dst = partial + static_cast<int64_t>(blockIdx.y) * n_frames * 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dst[t * 3 + i] = acc[i];
+  }
+}
+
+// Per atom: totals[b][a] becomes the sum of the blocks before b; carry[a] moves on to
+// the integral at the batch's last frame (carry_next), the old value staying in `carry`
+// for the second launch.
+__global__ __launch_bounds__(kThreads) void kinaci_offsets_kernel(
+    double *__restrict__ totals, int64_t n_blocks, int64_t n_atoms, double dt,
+    const double *__restrict__ carry, double *__restrict__ carry_next) {
+  const int64_t a = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (a >= n_atoms) return;
+  double run = 0.0;
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    const double own = totals[b * n_atoms + a];
+    totals[b * n_atoms + a] = run;
+    run = run + own;
+  }
+  carry_next[a] = carry[a] + run * dt;
+}
+
 // out[col] (+)= sum over chunks, in chunk order.  planes == 2 combines the two
 // partial sums of the thermal flux as (sum of plane 0) - (sum of plane 1).
 __global__ __launch_bounds__(kThreads) void combine_chunks_kernel(
@@ -506,6 +612,62 @@ int mdx_energy_weighted_sum(const void *x, const void *ke, const void *pe, int d
   MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,
                  accumulate, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
+int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
+                            const void *pe, int dtype, int location, int64_t n_atoms,
+                            int64_t n_frames, double dt, int have_carry, double *carry,
+                            double *out, int out_location, int accumulate) {
+  MDX_TRY(check_common(pos, dtype, location, n_atoms, n_frames, out, out_location));
+  MDX_REQUIRE(vel != nullptr && force != nullptr && pe != nullptr && carry != nullptr,
+              "null argument");
+  hipStream_t stream;
+  MDX_TRY(get_stream(&stream));
+  const int64_t n_cols = n_frames * 3;
+  if (n_atoms == 0) return zero_result(out, out_location, n_cols, accumulate, stream);
+  if (!have_carry)
+    for (int64_t a = 0; a < n_atoms; ++a) carry[a] = 0.0;
+  if (n_frames == 0) return MDX_OK;
+  DeviceBuffer st_x, st_v, st_f, st_p, partial, totals, d_carry, d_next;
+  const void *dx = nullptr, *dv = nullptr, *df = nullptr, *dp = nullptr;
+  const size_t unit = static_cast<size_t>(n_atoms) * n_frames * dtype_size(dtype);
+  MDX_TRY(to_device(pos, location, unit * 3, st_x, stream, &dx));
+  MDX_TRY(to_device(vel, location, unit * 3, st_v, stream, &dv));
+  MDX_TRY(to_device(force, location, unit * 3, st_f, stream, &df));
+  MDX_TRY(to_device(pe, location, unit, st_p, stream, &dp));
+  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
+  const size_t carry_bytes = sizeof(double) * static_cast<size_t>(n_atoms);
+  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
+  MDX_TRY(totals.alloc(carry_bytes * static_cast<size_t>(plan.col_blocks)));
+  MDX_TRY(d_carry.alloc(carry_bytes));
+  MDX_TRY(d_next.alloc(carry_bytes));
+  MDX_HIP(hipMemcpyAsync(d_carry.ptr, carry, carry_bytes, hipMemcpyHostToDevice, stream));
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  const unsigned atom_blocks = static_cast<unsigned>(ceil_div(n_atoms, kThreads));
+#define MDX_KINACI(TYPE)                                                                      \
+  do {                                                                                        \
+    hipLaunchKernelGGL((kinaci_kernel<TYPE, false>), grid, dim3(kThreads), 0, stream,         \
+                       static_cast<const TYPE *>(dx), static_cast<const TYPE *>(dv),          \
+                       static_cast<const TYPE *>(df), static_cast<const TYPE *>(dp), n_atoms, \
+                       n_frames, plan.atoms_per_chunk, dt, d_carry.as<double>(),              \
+                       totals.as<double>(), partial.as<double>());                            \
+    hipLaunchKernelGGL(kinaci_offsets_kernel, dim3(atom_blocks), dim3(kThreads), 0, stream,   \
+                       totals.as<double>(), plan.col_blocks, n_atoms, dt,                     \
+                       d_carry.as<double>(), d_next.as<double>());                            \
+    hipLaunchKernelGGL((kinaci_kernel<TYPE, true>), grid, dim3(kThreads), 0, stream,          \
+                       static_cast<const TYPE *>(dx), static_cast<const TYPE *>(dv),          \
+                       static_cast<const TYPE *>(df), static_cast<const TYPE *>(dp), n_atoms, \
+                       n_frames, plan.atoms_per_chunk, dt, d_carry.as<double>(),              \
+                       totals.as<double>(), partial.as<double>());                            \
+  } while (0)
+  if (dtype == MDX_F32) MDX_KINACI(float); else MDX_KINACI(double);
+#undef MDX_KINACI
+  MDX_HIP(hipGetLastError());
+  MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,
+                 accumulate, stream));
+  MDX_HIP(hipMemcpyAsync(carry, d_next.ptr, carry_bytes, hipMemcpyDeviceToHost, stream));
   MDX_HIP(hipStreamSynchronize(stream));
   return MDX_OK;
 }

@@ -378,6 +378,34 @@ def energy_weighted_sum(x: ArrayLike, ke: ArrayLike, pe: ArrayLike,
     return out
 
 
+def kinaci_heat_current(pos: ArrayLike, vel: ArrayLike, force: ArrayLike, pe: ArrayLike,
+                        dt: float, carry: Optional[np.ndarray] = None,
+                        out: Optional[np.ndarray] = None, accumulate: bool = False):
+    """``out[t, :] (+)= sum_a pos[a, t, :] * (I_a(t) + pe[a, t])`` with the running
+    integral ``I_a(t) = carry[a] + dt * cumsum_t(force[a] . vel[a])``; see
+    ``mdx_kinaci_heat_current``.  Returns ``(out, carry at the last frame)``."""
+    infos = [_as_input(a) for a in (pos, vel, force, pe)]
+    if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
+        raise ValueError("all inputs must share dtype and location")
+    n_atoms, n_frames = infos[0][3][0], infos[0][3][1]
+    for info, shp in zip(infos, [(n_atoms, n_frames, 3)] * 3 + [(n_atoms, n_frames, 1)]):
+        if tuple(info[3]) != shp:
+            raise ValueError(f"expected shape {shp}, got {info[3]}")
+    have_carry = carry is not None
+    if have_carry:
+        carry = np.array(carry, dtype=np.float64).reshape(-1)
+        if carry.shape[0] != n_atoms:
+            raise ValueError(f"carry must hold {n_atoms} values, got {carry.shape[0]}")
+    else:
+        carry = np.zeros(n_atoms, dtype=np.float64)
+    out = _out_buffer(out, (n_frames, 3), accumulate)
+    check(_lib.load().mdx_kinaci_heat_current(
+        infos[0][0], infos[1][0], infos[2][0], infos[3][0], infos[0][1], infos[0][2], n_atoms,
+        n_frames, float(dt), 1 if have_carry else 0, carry.ctypes.data, out.ctypes.data,
+        MDX_HOST, 1 if accumulate else 0))
+    return out, carry
+
+
 # ------------------------------------------------ angular distribution function
 
 def adf_accumulate(species_positions: Sequence[ArrayLike], box, cutoff: float,

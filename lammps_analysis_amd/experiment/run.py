@@ -59,6 +59,11 @@ class RunComputation:
         return self.transformation_wrapper(IntegratedHeatCurrent)
 
     @property
+    def KinaciIntegratedHeatCurrent(self):
+        from ..transformations import KinaciIntegratedHeatCurrent
+        return self.transformation_wrapper(KinaciIntegratedHeatCurrent)
+
+    @property
     def ThermalFlux(self):
         from ..transformations import ThermalFlux
         return self.transformation_wrapper(ThermalFlux)
@@ -149,6 +154,10 @@ class RunComputation:
     @property
     def EinsteinHelfandThermalConductivity(self):
         return self._calculator("EinsteinHelfandThermalConductivity")
+
+    @property
+    def EinsteinHelfandThermalKinaci(self):
+        return self._calculator("EinsteinHelfandThermalKinaci")
 
     @property
     def EinsteinHelfandIonicConductivity(self):

@@ -4,6 +4,7 @@ reference).  A list is tried in order until one finds its inputs."""
 from ..database.mdsuite_properties import mdsuite_properties as mdp
 from .integrated_heat_current import IntegratedHeatCurrent
 from .ionic_current import IonicCurrent
+from .kinaci_integrated_heat_current import KinaciIntegratedHeatCurrent
 from .momentum_flux import MomentumFlux
 from .scale_coordinates import ScaleCoordinates
 from .thermal_flux import ThermalFlux
@@ -16,6 +17,7 @@ from .wrap_coordinates import CoordinateWrapper
 property_to_transformation_dict = {
     mdp.integrated_heat_current: IntegratedHeatCurrent,
     mdp.ionic_current: IonicCurrent,
+    mdp.kinaci_heat_current: KinaciIntegratedHeatCurrent,
     mdp.momentum_flux: MomentumFlux,
     mdp.positions: [ScaleCoordinates, CoordinateWrapper],
     mdp.thermal_flux: ThermalFlux,

@@ -535,3 +535,28 @@ def integrated_heat_current(positions_by_species, ke_by_species, pe_by_species) 
                       * (np.asarray(ke, np.float64) + np.asarray(pe, np.float64)), axis=0)
         out = term if out is None else out + term
     return out
+
+
+def kinaci_heat_current(pos, vel, force, pe, time_step, sample_rate, carry=None):
+    """One species and one batch of mdsuite/transformations/
+    kinaci_integrated_heat_current.py:53-87, float64: ``integrand = einsum('ijk,ijk->ij',
+    force, vel)``, ``integral = carry[:, None] + cumsum(integrand, axis=1) * time_step *
+    sample_rate``, ``r_k = einsum('ijk,ij->jk', pos, integral)``, ``r_p =
+    einsum('ijk,ijm->jm', pe, pos)``; returns ``(r_k + r_p, integral[:, -1])``.
+
+    The integral is kept per atom of the species.  The reference text adds the integral
+    arrays of all species element by element (``tf.add_n(integrals)``), which only runs
+    when every species has the same number of atoms and has no test ("someone who
+    understands the transformation please provide a test", :90-91); that sum is not
+    restated.  Parity unpinned."""
+    pos = np.asarray(pos, np.float64)
+    vel = np.asarray(vel, np.float64)
+    force = np.asarray(force, np.float64)
+    pe = np.asarray(pe, np.float64)
+    integrand = np.einsum("ijk,ijk->ij", force, vel)
+    integral = np.cumsum(integrand, axis=1) * time_step * sample_rate
+    if carry is not None:
+        integral = np.asarray(carry, np.float64)[:, None] + integral
+    r_k = np.einsum("ijk,ij->jk", pos, integral)
+    r_p = np.einsum("ijk,ijm->jm", pe, pos)
+    return r_k + r_p, integral[:, -1].copy()

@@ -327,3 +327,52 @@ def test_einstein_helfand_thermal_conductivity(gpu, tmp_path):
     assert_close(res["msd"], msd)
     np.testing.assert_allclose(res["time"], np.arange(D) * 0.002)
     assert np.isfinite(res["thermal_conductivity"])
+
+
+def test_einstein_helfand_thermal_kinaci(gpu, tmp_path):
+    """Kinaci heat current (running integral of F.v per atom, then positions x (integral +
+    potential energy) reduced over atoms, both on the GPU) and the MSD-based thermal
+    conductivity built on it; the reference's own test of this calculator is disabled
+    (CI/integration_tests/calculators/_test_einstein_helfand_thermal_kinaci.py)."""
+    rng = np.random.default_rng(9)
+    box, n_step, D = 18.0, 600, 80
+    data = {}
+    for name, n in (("Na", 20), ("Cl", 14)):
+        data[name] = {
+            mdsuite_properties.unwrapped_positions:
+                np.cumsum(rng.normal(size=(n_step, n, 3)), axis=0) * 0.1,
+            mdsuite_properties.velocities: rng.normal(size=(n_step, n, 3)),
+            mdsuite_properties.forces: rng.normal(size=(n_step, n, 3)),
+            mdsuite_properties.potential_energy: -rng.random((n_step, n, 1)) * 2.0,
+        }
+    project = mds.Project(name="ehk_proj", storage_path=tmp_path)
+    exp = project.add_experiment("NaCl", timestep=0.002, temperature=1400.0, units="metal")
+    _add(exp, data, n_step, box_l=[box] * 3)
+    res = exp.run.EinsteinHelfandThermalKinaci(data_range=D, plot=False)["System"]
+
+    stored = {k: {p: np.swapaxes(v, 0, 1).astype(np.float32) for p, v in props.items()}
+              for k, props in data.items()}
+    current = np.zeros((n_step, 3))
+    for k in data:
+        part, _ = orc.kinaci_heat_current(
+            stored[k][mdsuite_properties.unwrapped_positions],
+            stored[k][mdsuite_properties.velocities], stored[k][mdsuite_properties.forces],
+            stored[k][mdsuite_properties.potential_energy], exp.time_step, exp.sample_rate)
+        current += part
+    series = orc.store_as_float32(current)[None]
+    u = mds.units.METAL
+    prefactor = (1 / (box**3 * 1400.0 * u.boltzmann)
+                 * (u.energy / u.length / u.time / u.temperature))
+    starts = orc.window_starts(n_step, D, 1)
+    msd = np.zeros(D)
+    for s in starts:
+        win = series[0, s:s + D].astype(np.float64)
+        msd += prefactor * np.sum((win - win[0]) ** 2, axis=1)
+    msd /= len(starts)
+    assert_close(res["msd"], msd)
+    np.testing.assert_allclose(res["time"], np.arange(D) * 0.002)
+    assert np.isfinite(res["thermal_conductivity"])
+    stored_series = exp.load_matrix(path=["Observables/Kinaci_Heat_Current"])
+    if isinstance(stored_series, dict):
+        stored_series = list(stored_series.values())[0]
+    assert_close(np.asarray(stored_series).reshape(n_step, 3), series[0])

@@ -312,3 +312,46 @@ def test_msd_three_components_small_lags_far_from_origin(gpu, dtype, offset, D):
     ref = c_oracle.msd_windows(pos.astype(np.float64), 1, 3, T - D, tau)
     assert got[0] == 0.0 and ref[0] == 0.0
     np.testing.assert_allclose(got[1:], ref[1:], rtol=1e-9, atol=0.0)
+
+
+# ------------------------------------------------- Kinaci integrated heat current
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_atoms,n_frames", [(1, 1), (5, 7), (33, 1000), (130, 257), (7, 2049)])
+def test_kinaci_heat_current_matches_oracle(gpu, dtype, n_atoms, n_frames):
+    """Running integral of force.velocity per atom (scanned over blocks of 256 frames on
+    the GPU) in front of the atom reduction; sizes around the block and chunk edges."""
+    rng = np.random.default_rng(31)
+    pos = np.cumsum(rng.normal(size=(n_atoms, n_frames, 3)), axis=1).astype(dtype)
+    vel = rng.normal(size=(n_atoms, n_frames, 3)).astype(dtype)
+    force = rng.normal(size=(n_atoms, n_frames, 3)).astype(dtype)
+    pe = -rng.random((n_atoms, n_frames, 1)).astype(dtype)
+    got, carry = gpu.kinaci_heat_current(pos, vel, force, pe, dt=0.002 * 5)
+    ref, ref_carry = orc.kinaci_heat_current(pos, vel, force, pe, 0.002, 5)
+    assert_close(got, ref, rtol=1e-12)
+    assert_close(carry, ref_carry, rtol=1e-12)
+
+
+def test_kinaci_heat_current_carries_the_integral_across_batches(gpu):
+    rng = np.random.default_rng(32)
+    n_atoms, n_frames = 40, 900
+    pos = np.cumsum(rng.normal(size=(n_atoms, n_frames, 3)), axis=1).astype(np.float32)
+    vel = rng.normal(size=(n_atoms, n_frames, 3)).astype(np.float32)
+    force = rng.normal(size=(n_atoms, n_frames, 3)).astype(np.float32)
+    pe = -rng.random((n_atoms, n_frames, 1)).astype(np.float32)
+    whole, whole_carry = orc.kinaci_heat_current(pos, vel, force, pe, 0.5, 2)
+    parts, carry, ref_carry = [], None, None
+    for lo, hi in ((0, 300), (300, 301), (301, 900)):
+        cut = [np.ascontiguousarray(a[:, lo:hi]) for a in (pos, vel, force, pe)]
+        part, carry = gpu.kinaci_heat_current(*cut, dt=1.0, carry=carry)
+        ref_part, ref_carry = orc.kinaci_heat_current(*cut, 0.5, 2, carry=ref_carry)
+        assert_close(part, ref_part, rtol=1e-12)
+        parts.append(part)
+    assert_close(np.concatenate(parts), whole, rtol=1e-12)
+    assert_close(carry, whole_carry, rtol=1e-12)
+    # a second species is added to the first one's frames
+    out, _ = gpu.kinaci_heat_current(pos, vel, force, pe, dt=1.0)
+    both, _ = gpu.kinaci_heat_current(pos[:9], vel[:9], force[:9], pe[:9], dt=1.0, out=out,
+                                      accumulate=True)
+    assert_close(both, whole + orc.kinaci_heat_current(pos[:9], vel[:9], force[:9], pe[:9],
+                                                       0.5, 2)[0], rtol=1e-12)
