@@ -491,6 +491,8 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "slide_kernel_ms": slide_ms / max(slide_n, 1),
         "band_kernel_tflops_f64": band_flops / (band_avg * 1e-3) / 1e12 if band_avg else None,
         "f64_vector_peak_tflops": 78.6,
+        "kernel": "band4_kernel<float, 33, false>",
+        "mfma_f64_sustained_tflops": 74.0,
     }
     # per-atom mean-square displacement of one species (EinsteinDiffusionCoefficients,
     # default data_range 100), on the same array read as positions
@@ -518,15 +520,17 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "frames_per_s": n_frames / dt_m,
         "ms_per_pass": dt_m * 1e3,
         "band_kernel_ms": msd_avg,
-        "kernel": "msd_band_mfma_kernel<float, 112>",
+        "kernel": "band4_kernel<float, 27, true>",
         # algorithmic count: subtract, multiply, add per origin, lag, atom and component
         "band_kernel_tflops_f64": (3.0 * n_frames * msd_range * N_NA * 3
                                    / (msd_avg * 1e-3) / 1e12) if msd_avg else None,
-        # what the matrix cores execute: 64-frame tiles x 128 columns (112 lags + the half
-        # tiles at both ends), 2 flops per element, row and component
-        "mfma_tflops_issued": (2.0 * 64 * math.ceil(n_frames / 64) * 128 * N_NA * 3
+        # what the matrix cores execute: 128-frame tiles x 27 lag blocks of 4, 2 flops per
+        # element, row and component
+        "mfma_tflops_issued": (2.0 * 128 * math.ceil(n_frames / 128) * 108 * N_NA * 3
                                / (msd_avg * 1e-3) / 1e12) if msd_avg else None,
-        "mfma_f64_sustained_tflops": 47.0,
+        # v_mfma_f64_4x4x4_4b_f64 back to back (scratch/mfma/clock.hip); the 16x16x4
+        # instruction sustains 48
+        "mfma_f64_sustained_tflops": 74.0,
     }
     vel_na.free()
     vel_cl.free()

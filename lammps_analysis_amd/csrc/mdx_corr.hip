@@ -1193,6 +1193,197 @@ void msd_band_mfma_kernel(
   }
 }
 
+// The same band on v_mfma_f64_4x4x4_4b_f64, which sustains 74 TFLOP/s on gfx950 where
+// the 16x16x4 instruction stops at 48 (scratch/mfma/clock.hip).  One instruction
+// multiplies four independent 4 x 4 x 4 blocks; lane l supplies A[blk][i][k] and
+// B[blk][k][j] with k = l / 16, blk = (l % 16) / 4, i or j = l % 4, and receives
+// D[blk][i][j] with i = l / 16, blk = (l % 16) / 4, j = l % 4 (scratch/mfma/probe4.hip).
+// An operand register therefore holds 16 consecutive frames of 4 rows, as for the larger
+// instruction: with A = own frames f.. and B = frames g.., block blk forms the products of
+// own frames f + 4 blk + i with frames g + 4 blk + j, i.e. the lags g - f + (j - i).
+// A wave owns 16 own frames (one A register per inner block) and walks B over the
+// shifted frames in steps of 4: b_u, frames 16 wave + 4 u.., gives the lags 4 u - 3 ..
+// 4 u + 3, accumulator acc[u] (one double per lane).  Every (own frame, lag) pair lands
+// in exactly one accumulator, so a tile of 128 frames x 4 (NQ - 1) lags costs 128 x 4 NQ
+// products per row: NQ = 27 covers 104 lags at 96 %.  Blocks have eight waves and a
+// compute unit holds two of them: four waves per SIMD keep the matrix pipe fed while
+// others stage or wait at the barrier (with two it idled 29 % of the time).
+// The image is staged as float64 (four series per round), so an operand goes from LDS
+// to the instruction with no conversion in between.  kMsd as in msd_band_mfma_kernel
+// (reference position per series and tile, here subtracted when the image is written;
+// squares by the staging threads; lag 0 exact); otherwise the products go to the band
+// table Q.
+constexpr int kB4Threads = 512;
+constexpr int kB4Series = 4;  // series per staging round
+constexpr int kB4Rows = 3 * kB4Series;
+template <int NQ>
+struct Band4 {
+  static constexpr int kT = (kB4Threads / 64) * 16;  // own frames per block
+  static constexpr int kM = 4 * (NQ - 1);            // lags per tile
+  static constexpr int kFrames = kT + (kT + kM);
+  static constexpr int kPerLane = (kFrames + 127) / 128;  // frames a thread stages per series
+  // ds_read_b64 serves lanes 0-31 in one cycle over 64 four-byte banks: the two rows of a
+  // half wave must start 32 banks (16 doubles) apart
+  static constexpr int kPitch = 128 * kPerLane + 16;
+  static constexpr int kStripPitch = kM + 1;
+  // the image is float64 whatever the input: operands go from LDS to the instruction
+  static size_t lds_bytes(bool msd) {
+    const size_t image = sizeof(double) * 2 * kB4Rows * kPitch;
+    const size_t finish = msd ? sizeof(double) * (4 * kFrames + kFrames + 32 * kStripPitch) : 0;
+    return image > finish ? image : finish;
+  }
+};
+
+template <typename T, int NQ, bool kMsd>
+__global__ __launch_bounds__(kB4Threads) __attribute__((amdgpu_waves_per_eu(4)))
+void band4_kernel(const T *__restrict__ x, int64_t n_series, int64_t n_frames, int64_t t0,
+                  int64_t t_len, int R, int64_t series_per_chunk, double *__restrict__ Q,
+                  int64_t tiles_t, int tiles_m, int n_chunks) {
+  using C = Band4<NQ>;
+  int64_t block_t;
+  int block_m, block_chunk;
+  if (!band_item(tiles_t, tiles_m, n_chunks, &block_t, &block_m, &block_chunk)) return;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  double(*img)[kB4Rows][C::kPitch] = reinterpret_cast<double(*)[kB4Rows][C::kPitch]>(lds_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t tile_t = block_t * C::kT;
+  const int tile_m = block_m * C::kM;
+  const int64_t s0 = static_cast<int64_t>(block_chunk) * series_per_chunk;
+  const int64_t s1 = min(n_series, s0 + series_per_chunk);
+
+  // staging: wave % 4 = series of the round, wave / 4 = half of the staged frames (the
+  // tile's own frames first, then the kT + kM frames from the tile's first lag on)
+  const int st_series = wave & 3;
+  const int st_first = (wave >> 2) * 64 * C::kPerLane + lane;
+  T pre[C::kPerLane][3];
+  T pre_ref[3];
+  auto fetch = [&](int64_t s_base) {
+    const int64_t s = s_base + st_series;
+    const T *series = x + s * n_frames * 3;
+#pragma unroll
+    for (int q = 0; q < C::kPerLane; ++q) {
+      const int f = st_first + 64 * q;
+      const int64_t frame = t0 + tile_t + ((f < C::kT) ? f : tile_m + (f - C::kT));
+      const bool live = s < s1 && f < C::kFrames && frame < n_frames;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) pre[q][d] = live ? series[frame * 3 + d] : T(0);
+    }
+    if (kMsd) {
+      // the series' position at the tile's first frame (one address per wave)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) pre_ref[d] = (s < s1) ? series[(t0 + tile_t) * 3 + d] : T(0);
+    }
+  };
+
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+  double sq[C::kPerLane];
+#pragma unroll
+  for (int q = 0; q < C::kPerLane; ++q) sq[q] = 0.0;
+
+  if (s0 < s1) fetch(s0);
+  int buf = 0;
+  const int kk = lane >> 4;
+  const int fr = lane & 15;
+  for (int64_t s_base = s0; s_base < s1; s_base += kB4Series) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double ref = kMsd ? static_cast<double>(pre_ref[d]) : 0.0;
+#pragma unroll
+      for (int q = 0; q < C::kPerLane; ++q) {
+        const double v = static_cast<double>(pre[q][d]) - ref;
+        img[buf][st_series * 3 + d][st_first + 64 * q] = v;
+        if (kMsd) sq[q] = fma(v, v, sq[q]);
+      }
+    }
+    __syncthreads();
+    if (s_base + kB4Series < s1) fetch(s_base + kB4Series);
+#pragma unroll
+    for (int g = 0; g < kB4Rows / 4; ++g) {
+      const double *row = img[buf][4 * g + kk];
+      const double a = row[16 * wave + fr];
+      const double *shifted = row + C::kT + 16 * wave + fr;
+      // B operands are read kAhead steps before their use; the scheduling fence keeps the
+      // compiler from hoisting more of them (and spilling accumulators to make room)
+      constexpr int kAhead = 6;
+      double b[NQ];
+#pragma unroll
+      for (int u = 0; u < kAhead && u < NQ; ++u) b[u] = shifted[4 * u];
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        if (u + kAhead < NQ) b[u + kAhead] = shifted[4 * (u + kAhead)];
+        // keeps the previous step's operand alive past this read, so that the read lands
+        // in a register whose last instruction was issued two steps ago, not just now
+        if (u > 0) asm volatile("" ::"v"(b[u - 1]));
+        acc[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[u], acc[u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    buf ^= 1;  // the other image was last read before this round's barrier
+  }
+
+  // result lane layout: own frame 4 blk + i, lag 4 u + j - i
+  const int ri = lane >> 4;
+  const int rblk = (lane & 15) >> 2;
+  const int rj = lane & 3;
+  if (!kMsd) {
+    double *out = Q + static_cast<int64_t>(block_chunk) * t_len * R;
+    const int64_t tt = tile_t + 16 * wave + 4 * rblk + ri;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int m_rel = 4 * q + rj - ri;
+      const int m = tile_m + m_rel;
+      if (m_rel >= 0 && m_rel < C::kM && m < R && tt < t_len) out[tt * R + m] = acc[q];
+    }
+    return;
+  }
+
+  // per staged frame: squares summed over the round's four series
+  __syncthreads();  // the images are no longer read
+  double *sqs = reinterpret_cast<double *>(lds_raw);  // [4][kFrames]
+  double *ssum = sqs + 4 * C::kFrames;                // [kFrames]
+  double *strip = ssum + C::kFrames;                  // [32 own frames][kStripPitch]
+#pragma unroll
+  for (int q = 0; q < C::kPerLane; ++q)
+    if (st_first + 64 * q < C::kFrames) sqs[st_series * C::kFrames + st_first + 64 * q] = sq[q];
+  __syncthreads();
+  for (int f = threadIdx.x; f < C::kFrames; f += kB4Threads)
+    ssum[f] = ((sqs[f] + sqs[C::kFrames + f]) + sqs[2 * C::kFrames + f]) + sqs[3 * C::kFrames + f];
+  // cross terms: lag m collects its diagonal, two waves' 32 own frames at a time, in a
+  // fixed order
+  double cross = 0.0;
+#pragma unroll
+  for (int pass = 0; pass < kB4Threads / 128; ++pass) {
+    __syncthreads();  // ssum written / the previous rows consumed
+    if ((wave >> 1) == pass) {
+      double *mine = strip + ((wave & 1) * 16 + 4 * rblk + ri) * C::kStripPitch;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int m_rel = 4 * q + rj - ri;
+        if (m_rel >= 0 && m_rel < C::kM) mine[m_rel] = acc[q];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < C::kM) {
+      for (int r = 0; r < 32; ++r)
+        if (tile_t + 32 * pass + r < t_len) cross = cross + strip[r * C::kStripPitch + threadIdx.x];
+    }
+  }
+  const int m = tile_m + static_cast<int>(threadIdx.x);
+  if (threadIdx.x < C::kM && m < R) {
+    double own_sum = 0.0, shifted_sum = 0.0;
+    for (int t = 0; t < C::kT; ++t)
+      if (tile_t + t < t_len) {
+        own_sum = own_sum + ssum[t];
+        shifted_sum = shifted_sum + ssum[C::kT + t + threadIdx.x];
+      }
+    const double value = (own_sum + shifted_sum) - 2.0 * cross;
+    Q[(static_cast<int64_t>(block_chunk) * tiles_t + block_t) * R + m] = (m == 0) ? 0.0 : value;
+  }
+}
+
 // ------------------------------------------------------------------------ MSD
 
 // partial[block][i] = sum over the block's windows and series of
@@ -1248,6 +1439,34 @@ __global__ __launch_bounds__(kThreads) void combine_blocks_kernel(
 }
 
 // ----------------------------------------------------------------- host side
+
+// Series chunks of a band launch with `tiles` blocks per chunk: at least `base` of them
+// (what fills the chip), and then the smallest count up to `most` whose last round of
+// resident blocks is at least 95 % full, or the fullest one (3 128 tiles on 512 resident
+// blocks run 7 rounds for 6.1 rounds of work; three chunks run 19 for 18.3).
+int64_t band_chunks(int64_t tiles, int64_t base, int64_t most) {
+  int cus = 256;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cus = prop.multiProcessorCount;
+  const int64_t resident = 2 * static_cast<int64_t>(cus);
+  if (base < 1) base = 1;
+  if (most < base) most = base;
+  int64_t best = base;
+  double best_fill = 0.0;
+  for (int64_t c = base; c <= most; ++c) {
+    const int64_t blocks = tiles * c;
+    const double fill = static_cast<double>(blocks) /
+                        static_cast<double>(ceil_div(blocks, resident) * resident);
+    if (fill > best_fill + 1e-9) {
+      best_fill = fill;
+      best = c;
+    }
+    if (fill >= 0.95) return c;
+  }
+  return best;
+}
 
 struct TauInfo {
   int D = 0;
@@ -1371,11 +1590,18 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
     int64_t n_chunks = 1, series_per_chunk = n_series;
     if (band) {
       // series chunks only as far as needed to fill the chip with band tiles
-      const int64_t tiles = ceil_div((n_win - 1) * correlation_time + R, kMfT) *
-                            ceil_div(R, kMfM);
-      n_chunks = ceil_div(2048, tiles);
-      if (n_chunks > n_series / 32) n_chunks = n_series / 32;
-      if (n_chunks > 16) n_chunks = 16;
+      const bool b4 = k == 3 && getenv("MDX_ACF_BAND_VALU") == nullptr &&
+                      getenv("MDX_BAND_MFMA16") == nullptr;
+      const int64_t tiles =
+          b4 ? ceil_div((n_win - 1) * correlation_time + R, Band4<33>::kT) *
+                   ceil_div(R, Band4<33>::kM)
+             : ceil_div((n_win - 1) * correlation_time + R, kMfT) * ceil_div(R, kMfM);
+      int64_t most = n_series / 32 < 16 ? n_series / 32 : 16;
+      // every chunk has its own plane of the table: stay within half the budget
+      const int64_t plane_bytes = ((n_win - 1) * correlation_time + R) * R * 8;
+      while (most > 1 && plane_bytes * most > (int64_t(1) << 30)) --most;
+      n_chunks = band_chunks(tiles, ceil_div(2048, tiles) < most ? ceil_div(2048, tiles) : most,
+                             most);
       if (n_chunks < 1) n_chunks = 1;
       series_per_chunk = ceil_div(n_series, n_chunks);
       n_chunks = ceil_div(n_series, series_per_chunk);
@@ -1449,8 +1675,25 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
                        R, series_per_chunk, d_C.as<double>(), mf_tiles_t,                    \
                        static_cast<int>(mf_tiles_m), static_cast<int>(n_chunks));            \
   } while (0)
+#define MDX_LAUNCH_BAND4(TYPE)                                                                \
+  do {                                                                                       \
+    using B4 = Band4<33>;                                                                    \
+    const size_t lds_b4 = B4::lds_bytes(false);                                              \
+    const int64_t b4_tiles_t = ceil_div(t_len, B4::kT), b4_tiles_m = ceil_div(R, B4::kM);    \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(band4_kernel<TYPE, 33, false>),                       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b4)));              \
+    hipLaunchKernelGGL((band4_kernel<TYPE, 33, false>),                                      \
+                       dim3(band_grid(b4_tiles_t, b4_tiles_m, n_chunks)), dim3(kB4Threads),  \
+                       lds_b4, stream, static_cast<const TYPE *>(dx), n_series, n_frames,    \
+                       t0, t_len, R, series_per_chunk, d_C.as<double>(), b4_tiles_t,         \
+                       static_cast<int>(b4_tiles_m), static_cast<int>(n_chunks));            \
+  } while (0)
         const bool mfma = (k == 3) && getenv("MDX_ACF_BAND_VALU") == nullptr;
-        if (dtype == MDX_F32) {
+        const bool mfma4 = mfma && getenv("MDX_BAND_MFMA16") == nullptr;
+        if (mfma4) {
+          if (dtype == MDX_F32) MDX_LAUNCH_BAND4(float); else MDX_LAUNCH_BAND4(double);
+        } else if (dtype == MDX_F32) {
           if (mfma) MDX_LAUNCH_BAND_MFMA(float);
           else if (k == 3) MDX_LAUNCH_BAND(float, 3);
           else MDX_LAUNCH_BAND(float, 0);
@@ -1459,6 +1702,7 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
           else if (k == 3) MDX_LAUNCH_BAND(double, 3);
           else MDX_LAUNCH_BAND(double, 0);
         }
+#undef MDX_LAUNCH_BAND4
 #undef MDX_LAUNCH_BAND_MFMA
 #undef MDX_LAUNCH_BAND
         MDX_HIP(hipGetLastError());
@@ -1877,15 +2121,21 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
     // three components go to the matrix cores unless MDX_MSD_BAND_VALU is set; their
     // lag tile is 112 (covers the default data_range of 100 with 8 tiles of 16), 128 or 256
     const bool mfma = (k == 3) && getenv("MDX_MSD_BAND_VALU") == nullptr;
-    const int mfma_m = R <= 112 ? 112 : (R <= 128 ? 128 : 256);
-    const int tile_t = mfma ? 64 : (narrow ? BandTile<16>::T : BandTile<32>::T);
+    // the 4x4x4 instruction unless MDX_BAND_MFMA16 asks for the 16x16x4 kernel
+    const bool mfma4 = mfma && getenv("MDX_BAND_MFMA16") == nullptr;
+    const int mfma_m = mfma4 ? (R <= Band4<27>::kM ? Band4<27>::kM : Band4<33>::kM)
+                             : (R <= 112 ? 112 : (R <= 128 ? 128 : 256));
+    const int tile_t = mfma4 ? Band4<33>::kT
+                             : (mfma ? 64 : (narrow ? BandTile<16>::T : BandTile<32>::T));
     const int tile_m = mfma ? mfma_m : (narrow ? BandTile<16>::M : BandTile<32>::M);
     const size_t elem = dtype_size(dtype);
     const size_t lds_q =
-        mfma ? (mfma_m == 112 ? MsdMf<112>::lds_bytes(elem)
-                              : (mfma_m == 128 ? MsdMf<128>::lds_bytes(elem)
-                                               : MsdMf<256>::lds_bytes(elem)))
-             : (narrow ? BandTile<16>::lds_bytes(k) : BandTile<32>::lds_bytes(k));
+        mfma4 ? (mfma_m == Band4<27>::kM ? Band4<27>::lds_bytes(true)
+                                         : Band4<33>::lds_bytes(true))
+        : mfma ? (mfma_m == 112 ? MsdMf<112>::lds_bytes(elem)
+                                : (mfma_m == 128 ? MsdMf<128>::lds_bytes(elem)
+                                                 : MsdMf<256>::lds_bytes(elem)))
+               : (narrow ? BandTile<16>::lds_bytes(k) : BandTile<32>::lds_bytes(k));
     const int64_t tiles_t = ceil_div(n_win, tile_t);
     const int64_t tiles_m = ceil_div(R, tile_m);
     // enough blocks that the last, partly filled round of resident blocks is a small share
@@ -1927,7 +2177,25 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
                        n_win, R, series_per_chunk, d_partial.as<double>(), tiles_t,          \
                        static_cast<int>(tiles_m), static_cast<int>(n_chunks));               \
   } while (0)
-      if (mfma) {
+#define MDX_LAUNCH_MSD_BAND4(TYPE, NQQ)                                                       \
+  do {                                                                                       \
+    MDX_HIP(hipFuncSetAttribute(                                                             \
+        reinterpret_cast<const void *>(band4_kernel<TYPE, NQQ, true>),                       \
+        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_q)));               \
+    hipLaunchKernelGGL((band4_kernel<TYPE, NQQ, true>), grid_q, dim3(kB4Threads), lds_q,       \
+                       stream, static_cast<const TYPE *>(dx), n_series, n_frames, win_begin, \
+                       n_win, R, series_per_chunk, d_partial.as<double>(), tiles_t,          \
+                       static_cast<int>(tiles_m), static_cast<int>(n_chunks));               \
+  } while (0)
+      if (mfma4) {
+        if (dtype == MDX_F32) {
+          if (mfma_m == Band4<27>::kM) MDX_LAUNCH_MSD_BAND4(float, 27);
+          else MDX_LAUNCH_MSD_BAND4(float, 33);
+        } else {
+          if (mfma_m == Band4<27>::kM) MDX_LAUNCH_MSD_BAND4(double, 27);
+          else MDX_LAUNCH_MSD_BAND4(double, 33);
+        }
+      } else if (mfma) {
         if (dtype == MDX_F32) {
           if (mfma_m == 112) MDX_LAUNCH_MSD_MFMA(float, 112);
           else if (mfma_m == 128) MDX_LAUNCH_MSD_MFMA(float, 128);
@@ -1942,6 +2210,7 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
       } else {
         if (narrow) MDX_LAUNCH_MSD_BAND_K(double, 16); else MDX_LAUNCH_MSD_BAND_K(double, 32);
       }
+#undef MDX_LAUNCH_MSD_BAND4
 #undef MDX_LAUNCH_MSD_MFMA
 #undef MDX_LAUNCH_MSD_BAND_K
 #undef MDX_LAUNCH_MSD_BAND

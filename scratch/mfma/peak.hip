@@ -39,5 +39,7 @@ int main() {
   run<17>(256 * 2, 5000);
   run<8>(256 * 4, 10000);
   run<8>(256 * 1, 10000);
+  run<8>(256 * 4, 100000);  // 140 ms: the rate once clocks have settled
+  run<8>(256 * 2, 100000);
   return 0;
 }
