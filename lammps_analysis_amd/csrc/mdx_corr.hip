@@ -2139,8 +2139,17 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
     const int64_t tiles_t = ceil_div(n_win, tile_t);
     const int64_t tiles_m = ceil_div(R, tile_m);
     // enough blocks that the last, partly filled round of resident blocks is a small share
-    int64_t n_chunks = ceil_div(mfma ? 16384 : 2048, tiles_t * tiles_m);
-    if (n_chunks > n_series / 8) n_chunks = n_series / 8;
+    // enough blocks to fill the chip several times over, the last round of resident blocks
+    // nearly full, and blocks long enough that their start and the final sums stay small
+    int64_t n_chunks;
+    if (mfma) {
+      const int64_t most = n_series / 8 < 64 ? n_series / 8 : 64;
+      const int64_t base = ceil_div(4096, tiles_t * tiles_m);
+      n_chunks = band_chunks(tiles_t * tiles_m, base < most ? base : most, most);
+    } else {
+      n_chunks = ceil_div(2048, tiles_t * tiles_m);
+      if (n_chunks > n_series / 8) n_chunks = n_series / 8;
+    }
     if (n_chunks > 65535) n_chunks = 65535;
     if (n_chunks < 1) n_chunks = 1;
     int64_t series_per_chunk = ceil_div(n_series, n_chunks);
