@@ -103,3 +103,35 @@ def test_large_host_arrays_take_the_page_locked_upload_path(gpu):
     small = gpu.weighted_atom_sum(x[:, :100].copy(), scalar_weight=1.0)
     np.testing.assert_array_equal(got[:100], small)
     np.testing.assert_allclose(got, x.astype(np.float64).sum(axis=0), rtol=1e-12)
+
+
+@pytest.mark.parametrize("what,data_range", [("msd", 100), ("msd", 300), ("acf", 500)])
+def test_band_kernels_agree_at_size(gpu, monkeypatch, what, data_range):
+    """Per-atom MSD / VACF of 3 000 atoms x 20 000 frames through the three band kernels
+    (4x4x4 matrix instruction, 16x16x4 matrix instruction, vector unit): different tilings
+    and, for the MSD, the expanded square against the literal one.  The small-size tests
+    hold each of them to the oracle; here they must agree where the oracle cannot go."""
+    n_atoms, n_frames = 3000, 20000
+    x = gpu.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    x.fill_langevin(11, 0.05, 1.0)
+    tau = np.arange(data_range)
+
+    def run():
+        if what == "msd":
+            return gpu.msd_windows(x, 1, 0, n_frames - data_range, tau)
+        return gpu.acf_windows(x, 1, 0, n_frames - data_range, tau)[0]
+
+    results = {}
+    for name, env in (("mfma4", {}), ("mfma16", {"MDX_BAND_MFMA16": "1"}),
+                      ("valu", {"MDX_MSD_BAND_VALU": "1", "MDX_ACF_BAND_VALU": "1"})):
+        for key in ("MDX_BAND_MFMA16", "MDX_MSD_BAND_VALU", "MDX_ACF_BAND_VALU"):
+            monkeypatch.delenv(key, raising=False)
+        for key, value in env.items():
+            monkeypatch.setenv(key, value)
+        results[name] = run()
+    x.free()
+    scale = np.max(np.abs(results["valu"]))
+    for name in ("mfma4", "mfma16"):
+        np.testing.assert_allclose(results[name], results["valu"], rtol=0.0, atol=1e-12 * scale)
+    if what == "msd":
+        assert results["mfma4"][0] == 0.0
