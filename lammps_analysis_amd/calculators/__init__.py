@@ -14,6 +14,7 @@ from .green_kubo_thermal_conductivity import GreenKuboThermalConductivity
 from .green_kubo_viscosity import GreenKuboViscosity
 from .green_kubo_viscosity_flux import GreenKuboViscosityFlux
 from .kirkwood_buff_integrals import KirkwoodBuffIntegral
+from .nernst_einstein_ionic_conductivity import NernstEinsteinIonicConductivity
 from .potential_of_mean_force import PotentialOfMeanForce
 from .radial_distribution_function import RadialDistributionFunction
 
@@ -23,4 +24,4 @@ __all__ = ["AngularDistributionFunction", "CoordinationNumbers", "KirkwoodBuffIn
            "EinsteinHelfandThermalConductivity", "EinsteinHelfandThermalKinaci",
            "GreenKuboIonicConductivity", "GreenKuboDiffusionCoefficients",
            "GreenKuboThermalConductivity", "GreenKuboViscosity", "GreenKuboViscosityFlux",
-           "RadialDistributionFunction"]
+           "RadialDistributionFunction", "NernstEinsteinIonicConductivity"]

@@ -156,6 +156,10 @@ class RunComputation:
         return self._calculator("EinsteinHelfandThermalConductivity")
 
     @property
+    def NernstEinsteinIonicConductivity(self):
+        return self._calculator("NernstEinsteinIonicConductivity")
+
+    @property
     def EinsteinHelfandThermalKinaci(self):
         return self._calculator("EinsteinHelfandThermalKinaci")
 

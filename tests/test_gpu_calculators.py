@@ -376,3 +376,45 @@ def test_einstein_helfand_thermal_kinaci(gpu, tmp_path):
     if isinstance(stored_series, dict):
         stored_series = list(stored_series.values())[0]
     assert_close(np.asarray(stored_series).reshape(n_step, 3), series[0])
+
+
+def test_nernst_einstein_ionic_conductivity(gpu, tmp_path):
+    """Nernst-Einstein conductivity from the GPU-computed Einstein self-diffusion
+    coefficients, and its correction by the distinct coefficients
+    (mdsuite/calculators/nernst_einstein_ionic_conductivity.py:172-266; the reference
+    has no enabled test for it)."""
+    rng = np.random.default_rng(12)
+    box, n_step, D = 20.0, 900, 60
+    data = {name: {mdsuite_properties.unwrapped_positions:
+                   np.cumsum(rng.normal(size=(n_step, n, 3)), axis=0) * scale}
+            for name, n, scale in (("Na", 12, 0.1), ("Cl", 20, 0.05))}
+    charges = {"Na": 1.0, "Cl": -2.0}
+    project = mds.Project(name="ne_proj", storage_path=tmp_path)
+    exp = project.add_experiment("NaCl", timestep=0.002, temperature=1400.0, units="metal")
+    _add(exp, data, n_step, box_l=[box] * 3, charges=charges)
+    diffusion = exp.run.EinsteinDiffusionCoefficients(plot=False, data_range=D)
+    res = exp.run.NernstEinsteinIonicConductivity(diffusion_data=diffusion)["System"]
+
+    u = mds.units.METAL
+    n_atoms = 32
+    prefactor = (n_atoms * mds.utils.units.elementary_charge**2
+                 / (mds.utils.units.boltzmann_constant * 1400.0 * box**3 * u.volume))
+    weights = {name: charges[name] ** 2 * n / n_atoms for name, n in (("Na", 12), ("Cl", 20))}
+    want = prefactor * sum(diffusion[name]["diffusion_coefficient"] * w
+                           for name, w in weights.items())
+    want_err = prefactor * sum(diffusion[name]["uncertainty"] * w for name, w in weights.items())
+    np.testing.assert_allclose(res["ionic_conductivity"], want, rtol=1e-12)
+    np.testing.assert_allclose(res["uncertainty"], want_err, rtol=1e-12)
+
+    distinct = exp.run.EinsteinDistinctDiffusionCoefficients(plot=False, data_range=D)
+    corrected = exp.run.NernstEinsteinIonicConductivity(
+        diffusion_data=diffusion, distinct_diffusion_data=distinct, corrected=True)["System"]
+    extra = 0.0
+    for pair, entry in distinct.data_dict.items():
+        a, b = pair.split("_")
+        extra += (entry["diffusion_coefficient"] * charges[a] * charges[b]
+                  * ({"Na": 12, "Cl": 20}[a] / n_atoms) * ({"Na": 12, "Cl": 20}[b] / n_atoms))
+    np.testing.assert_allclose(corrected["ionic_conductivity"], want + prefactor * extra,
+                               rtol=1e-12)
+    with pytest.raises(ValueError):
+        exp.run.NernstEinsteinIonicConductivity(diffusion_data=diffusion, species=["K"])
