@@ -1252,50 +1252,109 @@ void band4_kernel(const T *__restrict__ x, int64_t n_series, int64_t n_frames, i
   const int64_t s0 = static_cast<int64_t>(block_chunk) * series_per_chunk;
   const int64_t s1 = min(n_series, s0 + series_per_chunk);
 
-  // staging: wave % 4 = series of the round, wave / 4 = half of the staged frames (the
-  // tile's own frames first, then the kT + kM frames from the tile's first lag on)
+  // Staging of float32 input: a pair of waves takes one series of the round, a lane four
+  // adjacent staged frames (the tile's own frames first, then the kT + kM frames from the
+  // tile's first lag on): 48 contiguous bytes, three 16-byte buffer loads, and per
+  // component four adjacent doubles of the image, two 16-byte stores.  Memory
+  // instructions next to the matrix instructions cost the loop far more than their bytes
+  // (scratch/mfma/lds_mfma.hip), so a round issues 18 + 36 of them per block instead of
+  // 48 + 48.  The buffer descriptor covers one series: frames past its end, the lanes
+  // past the last group and series past the chunk read as zero.
+  constexpr bool kQuad = sizeof(T) == 4;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u3v __attribute__((ext_vector_type(3)));
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const int q_series = __builtin_amdgcn_readfirstlane(wave >> 1);
+  const int q_group = (wave & 1) * 64 + lane;
+  const bool q_active = q_group < C::kFrames / 4;
+  const int q_f = 4 * q_group;
+  const unsigned series_bytes = static_cast<unsigned>(n_frames * 12);
+  const unsigned q_offset =
+      q_active ? static_cast<unsigned>(
+                     (t0 + tile_t + ((q_f < C::kT) ? q_f : tile_m + (q_f - C::kT))) * 12)
+               : series_bytes;
+  u4v pre4[3];
+  u3v ref3;
+  // Staging of float64 input: wave % 4 = series of the round, wave / 4 = half of the staged
+  // frames, lane = frames lane + 64 q.
   const int st_series = wave & 3;
   const int st_first = (wave >> 2) * 64 * C::kPerLane + lane;
   T pre[C::kPerLane][3];
   T pre_ref[3];
   auto fetch = [&](int64_t s_base) {
-    const int64_t s = s_base + st_series;
-    const T *series = x + s * n_frames * 3;
+    if constexpr (kQuad) {
+      const int64_t s = s_base + q_series;
+      const bool there = s < s1;
+      const T *series = x + (there ? s : s0) * n_frames * 3;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<T *>(series), 0, there ? static_cast<int>(series_bytes) : 0, 0x00020000);
 #pragma unroll
-    for (int q = 0; q < C::kPerLane; ++q) {
-      const int f = st_first + 64 * q;
-      const int64_t frame = t0 + tile_t + ((f < C::kT) ? f : tile_m + (f - C::kT));
-      const bool live = s < s1 && f < C::kFrames && frame < n_frames;
+      for (int j = 0; j < 3; ++j)
+        pre4[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(q_offset) + 16 * j,
+                                                        0, 0);
+      if (kMsd)  // the series' position at the tile's first frame (one address per wave)
+        ref3 = __builtin_amdgcn_raw_buffer_load_b96(rsrc, static_cast<int>((t0 + tile_t) * 12),
+                                                    0, 0);
+    } else {
+      const int64_t s = s_base + st_series;
+      const T *series = x + s * n_frames * 3;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) pre[q][d] = live ? series[frame * 3 + d] : T(0);
-    }
-    if (kMsd) {
-      // the series' position at the tile's first frame (one address per wave)
+      for (int q = 0; q < C::kPerLane; ++q) {
+        const int f = st_first + 64 * q;
+        const int64_t frame = t0 + tile_t + ((f < C::kT) ? f : tile_m + (f - C::kT));
+        const bool live = s < s1 && f < C::kFrames && frame < n_frames;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) pre_ref[d] = (s < s1) ? series[(t0 + tile_t) * 3 + d] : T(0);
+        for (int d = 0; d < 3; ++d) pre[q][d] = live ? series[frame * 3 + d] : T(0);
+      }
+      if (kMsd) {
+        // the series' position at the tile's first frame (one address per wave)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pre_ref[d] = (s < s1) ? series[(t0 + tile_t) * 3 + d] : T(0);
+      }
     }
   };
 
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-  double sq[C::kPerLane];
-#pragma unroll
-  for (int q = 0; q < C::kPerLane; ++q) sq[q] = 0.0;
+  static_assert(C::kPerLane <= 4, "sq holds four staged frames per lane");
+  double sq[4] = {0.0, 0.0, 0.0, 0.0};
 
   if (s0 < s1) fetch(s0);
   int buf = 0;
   const int kk = lane >> 4;
   const int fr = lane & 15;
   for (int64_t s_base = s0; s_base < s1; s_base += kB4Series) {
+    if constexpr (kQuad) {
+      if (q_active) {
+        const unsigned word[12] = {pre4[0].x, pre4[0].y, pre4[0].z, pre4[0].w,
+                                   pre4[1].x, pre4[1].y, pre4[1].z, pre4[1].w,
+                                   pre4[2].x, pre4[2].y, pre4[2].z, pre4[2].w};
+        const unsigned ref_word[3] = {ref3.x, ref3.y, ref3.z};
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const double ref = kMsd ? static_cast<double>(pre_ref[d]) : 0.0;
+        for (int d = 0; d < 3; ++d) {
+          const double ref = kMsd ? static_cast<double>(__uint_as_float(ref_word[d])) : 0.0;
+          double v[4];
 #pragma unroll
-      for (int q = 0; q < C::kPerLane; ++q) {
-        const double v = static_cast<double>(pre[q][d]) - ref;
-        img[buf][st_series * 3 + d][st_first + 64 * q] = v;
-        if (kMsd) sq[q] = fma(v, v, sq[q]);
+          for (int i = 0; i < 4; ++i) {
+            v[i] = static_cast<double>(__uint_as_float(word[3 * i + d])) - ref;
+            if (kMsd) sq[i] = fma(v[i], v[i], sq[i]);
+          }
+          d2v *dst = reinterpret_cast<d2v *>(&img[buf][q_series * 3 + d][q_f]);
+          dst[0] = d2v{v[0], v[1]};
+          dst[1] = d2v{v[2], v[3]};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double ref = kMsd ? static_cast<double>(pre_ref[d]) : 0.0;
+#pragma unroll
+        for (int q = 0; q < C::kPerLane; ++q) {
+          const double v = static_cast<double>(pre[q][d]) - ref;
+          img[buf][st_series * 3 + d][st_first + 64 * q] = v;
+          if (kMsd) sq[q] = fma(v, v, sq[q]);
+        }
       }
     }
     __syncthreads();
@@ -1345,9 +1404,16 @@ void band4_kernel(const T *__restrict__ x, int64_t n_series, int64_t n_frames, i
   double *sqs = reinterpret_cast<double *>(lds_raw);  // [4][kFrames]
   double *ssum = sqs + 4 * C::kFrames;                // [kFrames]
   double *strip = ssum + C::kFrames;                  // [32 own frames][kStripPitch]
+  if constexpr (kQuad) {
+    if (q_active) {
 #pragma unroll
-  for (int q = 0; q < C::kPerLane; ++q)
-    if (st_first + 64 * q < C::kFrames) sqs[st_series * C::kFrames + st_first + 64 * q] = sq[q];
+      for (int i = 0; i < 4; ++i) sqs[q_series * C::kFrames + q_f + i] = sq[i];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < C::kPerLane; ++q)
+      if (st_first + 64 * q < C::kFrames) sqs[st_series * C::kFrames + st_first + 64 * q] = sq[q];
+  }
   __syncthreads();
   for (int f = threadIdx.x; f < C::kFrames; f += kB4Threads)
     ssum[f] = ((sqs[f] + sqs[C::kFrames + f]) + sqs[2 * C::kFrames + f]) + sqs[3 * C::kFrames + f];
@@ -1591,7 +1657,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
     if (band) {
       // series chunks only as far as needed to fill the chip with band tiles
       const bool b4 = k == 3 && getenv("MDX_ACF_BAND_VALU") == nullptr &&
-                      getenv("MDX_BAND_MFMA16") == nullptr;
+                      getenv("MDX_BAND_MFMA16") == nullptr &&
+                      (dtype != MDX_F32 || n_frames * 12 < (int64_t(1) << 31));
       const int64_t tiles =
           b4 ? ceil_div((n_win - 1) * correlation_time + R, Band4<33>::kT) *
                    ceil_div(R, Band4<33>::kM)
@@ -1690,7 +1757,8 @@ int slide_windows(const SlideJob &job, hipStream_t stream, DeviceBuffer &d_C,
                        static_cast<int>(b4_tiles_m), static_cast<int>(n_chunks));            \
   } while (0)
         const bool mfma = (k == 3) && getenv("MDX_ACF_BAND_VALU") == nullptr;
-        const bool mfma4 = mfma && getenv("MDX_BAND_MFMA16") == nullptr;
+        const bool mfma4 = mfma && getenv("MDX_BAND_MFMA16") == nullptr &&
+                           (dtype != MDX_F32 || n_frames * 12 < (int64_t(1) << 31));
         if (mfma4) {
           if (dtype == MDX_F32) MDX_LAUNCH_BAND4(float); else MDX_LAUNCH_BAND4(double);
         } else if (dtype == MDX_F32) {
@@ -2122,7 +2190,9 @@ int mdx_msd_windows(const void *x, int dtype, int location, int64_t n_series,
     // lag tile is 112 (covers the default data_range of 100 with 8 tiles of 16), 128 or 256
     const bool mfma = (k == 3) && getenv("MDX_MSD_BAND_VALU") == nullptr;
     // the 4x4x4 instruction unless MDX_BAND_MFMA16 asks for the 16x16x4 kernel
-    const bool mfma4 = mfma && getenv("MDX_BAND_MFMA16") == nullptr;
+    // (its float32 staging addresses a series through a 32-bit buffer offset)
+    const bool mfma4 = mfma && getenv("MDX_BAND_MFMA16") == nullptr &&
+                       (dtype != MDX_F32 || n_frames * 12 < (int64_t(1) << 31));
     const int mfma_m = mfma4 ? (R <= Band4<27>::kM ? Band4<27>::kM : Band4<33>::kM)
                              : (R <= 112 ? 112 : (R <= 128 ? 128 : 256));
     const int tile_t = mfma4 ? Band4<33>::kT

@@ -284,6 +284,8 @@ def test_msd_subsampled_tau_and_scale(gpu):
     (9, 500, 100, 3, 37, np.float64),      # narrow lag tile, window range with an offset
     (12, 400, 40, 2, 0, np.float32),       # two components
     (64, 300, 17, 1, 5, np.float64),       # scalar series, several series chunks
+    (12, 503, 100, 3, 37, np.float32),     # float32: a four-frame load straddles the array end
+    (10, 1001, 130, 3, 3, np.float32),     # the same with the wider lag tile
 ])
 def test_msd_band_path_many_series(gpu, S, T, D, k, begin, dtype):
     """Consecutive origins, every lag and at least 8 series: squared displacements of a
@@ -355,3 +357,16 @@ def test_kinaci_heat_current_carries_the_integral_across_batches(gpu):
                                       accumulate=True)
     assert_close(both, whole + orc.kinaci_heat_current(pos[:9], vel[:9], force[:9], pe[:9],
                                                        0.5, 2)[0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("T,D,begin", [(1001, 128, 3), (777, 40, 1), (2050, 300, 5)])
+def test_acf_band_float32_ragged_end(gpu, T, D, begin):
+    """Three-component float32 series whose frame count, first window and lag range leave
+    the last staged frames of a tile half inside the array: the staging reads four frames
+    per lane and must take the part past the end as absent."""
+    rng = np.random.default_rng(41)
+    v = (rng.normal(size=(16, T, 3)) + 0.2).astype(np.float32)
+    tau = np.arange(D)
+    end = T - D + 1
+    acf, _ = gpu.acf_windows(v, 1, begin, end, tau)
+    assert_close(acf, c_oracle.acf_windows(v.astype(np.float64), 1, begin, end, tau), rtol=1e-10)
