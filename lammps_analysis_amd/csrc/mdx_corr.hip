@@ -1359,26 +1359,37 @@ void band4_kernel(const T *__restrict__ x, int64_t n_series, int64_t n_frames, i
     }
     __syncthreads();
     if (s_base + kB4Series < s1) fetch(s_base + kB4Series);
+    // The round's products as one stream of 3 NQ steps (inner block g = step / NQ, lag
+    // block u = step % NQ).  B operands are read kAhead steps before their use, across the
+    // inner blocks' edges (all waves reach those together: operands requested only there
+    // would leave the matrix pipe idle for an LDS latency three more times per round); the
+    // scheduling fence keeps the compiler from hoisting more reads (and spilling
+    // accumulators to make room).
+    constexpr int kAhead = 6;
+    constexpr int kSteps = (kB4Rows / 4) * NQ;
+    const double *own = &img[buf][kk][16 * wave + fr];
+    const double *shifted = own + C::kT;
+    auto operand_b = [&](int step) {
+      return shifted[(step / NQ) * 4 * C::kPitch + 4 * (step % NQ)];
+    };
+    double a[kB4Rows / 4];
+    double b[kSteps];
+    a[0] = own[0];
 #pragma unroll
-    for (int g = 0; g < kB4Rows / 4; ++g) {
-      const double *row = img[buf][4 * g + kk];
-      const double a = row[16 * wave + fr];
-      const double *shifted = row + C::kT + 16 * wave + fr;
-      // B operands are read kAhead steps before their use; the scheduling fence keeps the
-      // compiler from hoisting more of them (and spilling accumulators to make room)
-      constexpr int kAhead = 6;
-      double b[NQ];
+    for (int step = 0; step < kAhead; ++step) b[step] = operand_b(step);
 #pragma unroll
-      for (int u = 0; u < kAhead && u < NQ; ++u) b[u] = shifted[4 * u];
-#pragma unroll
-      for (int u = 0; u < NQ; ++u) {
-        if (u + kAhead < NQ) b[u + kAhead] = shifted[4 * (u + kAhead)];
-        // keeps the previous step's operand alive past this read, so that the read lands
-        // in a register whose last instruction was issued two steps ago, not just now
-        if (u > 0) asm volatile("" ::"v"(b[u - 1]));
-        acc[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[u], acc[u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int step = 0; step < kSteps; ++step) {
+      if (step + kAhead < kSteps) {
+        b[step + kAhead] = operand_b(step + kAhead);
+        if ((step + kAhead) % NQ == 0)
+          a[(step + kAhead) / NQ] = own[((step + kAhead) / NQ) * 4 * C::kPitch];
       }
+      // keeps the previous step's operand alive past this read, so that the read lands
+      // in a register whose last instruction was issued two steps ago, not just now
+      if (step > 0) asm volatile("" ::"v"(b[step - 1]));
+      acc[step % NQ] =
+          __builtin_amdgcn_mfma_f64_4x4x4f64(a[step / NQ], b[step], acc[step % NQ], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     buf ^= 1;  // the other image was last read before this round's barrier
   }
