@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: two or three processes joined through the library's own host
+"""Multi-rank path on CPU: two, three or eight processes joined through the library's own host
 transport (``lammps_analysis_amd.parallel``; no GPU here, so no RCCL).
 
 Each rank takes its share of the units (windows / tiles / frames) exactly as the
@@ -13,7 +13,7 @@ import _rank_workers as rw
 from lammps_analysis_amd import parallel
 
 
-@pytest.mark.parametrize("world", (2, 3))
+@pytest.mark.parametrize("world", (2, 3, 8))
 def test_exchange_step_matches_single_process(world):
     results = rw.run_ranks(rw.exchange, world)
     rng = np.random.default_rng(42)
