@@ -92,7 +92,8 @@ int mdx_event_destroy(mdx_event_t ev);
 #define MDX_SLOT_ACF_PARTIAL 3
 #define MDX_SLOT_ACF_FINISH 4
 #define MDX_SLOT_MSD 5
-#define MDX_NUM_SLOTS 6
+#define MDX_SLOT_FLUX 6 /* momentum / thermal flux, energy-weighted sum */
+#define MDX_NUM_SLOTS 7
 int mdx_profile_enable(int on);
 int mdx_profile_reset(void);
 int mdx_profile_query(int slot, double *total_ms, int64_t *launches);
@@ -168,6 +169,37 @@ int mdx_rdf_accumulate(mdx_rdf_t handle, const void *const *species_pos, int dty
                        int64_t n_frames, int shard_rank, int shard_count);
 /* Copy the histograms [n_keys][nbins] (uint64 counts) to the host; synchronises. */
 int mdx_rdf_read(mdx_rdf_t handle, uint64_t *hist);
+/*
+ * The constants of the default pair kernel for one geometry, computed on the host (no
+ * device is touched).  That kernel does not perform the float32 operations of get_dij /
+ * tf.histogram_fixed_width (radial_distribution_function.py:647-689, :642-644) one by
+ * one: per pair it forms
+ *     m_c  = half_box[c] - | |x_j[c] - x_i[c]| - half_box[c] |          (c = 0..2)
+ *     bits = float_bits( fma( v_sqrt_f32( fma(m_2, m_2, fma(m_1, m_1, m_0 * m_0)) ),
+ *                             scale, magic ) )
+ * with magic = 2^k + shift, so that bits & 0x7FFFFF, read as a fixed-point number with
+ * frac_bits fraction bits, is the pair's bin position plus shift.  The pair is dropped when
+ * bits >= keep_bits, counted in bin (bits & 0x7FFFFF) >> frac_bits otherwise, and
+ * evaluated again with the literal operations when the fraction bits are below
+ * edge_units.  The counts equal the literal ones as long as the position error stays
+ * below shift = edge_units / 2 grid units; this entry point lets a host-side model check
+ * that bound against the library's own constants.  usable == 0: the geometry does not
+ * admit the kernel (too many bins for the mantissa, degenerate box) and the table kernel
+ * runs instead.  step and s_cut are the literal rule's bin width and the smallest float32
+ * squared distance that fails d < cutoff.
+ */
+typedef struct {
+  int usable;
+  int frac_bits;
+  uint32_t edge_units;
+  uint32_t keep_bits;
+  float magic;
+  float scale;
+  float s_cut;
+  float half_box[3];
+  double step;
+} mdx_rdf_fast_plan_t;
+int mdx_rdf_fast_plan(const float box[3], float cutoff, int nbins, mdx_rdf_fast_plan_t *plan);
 
 /* --------------------------------------------------------- multi-GPU exchange */
 /*

@@ -50,6 +50,17 @@ c_u64_p = ctypes.POINTER(ctypes.c_uint64)
 c_f32_p = ctypes.POINTER(ctypes.c_float)
 c_f64_p = ctypes.POINTER(ctypes.c_double)
 
+
+class RdfFastPlan(ctypes.Structure):
+    """``mdx_rdf_fast_plan_t`` of include/mdx.h."""
+
+    _fields_ = [("usable", ctypes.c_int), ("frac_bits", ctypes.c_int),
+                ("edge_units", ctypes.c_uint32), ("keep_bits", ctypes.c_uint32),
+                ("magic", ctypes.c_float), ("scale", ctypes.c_float),
+                ("s_cut", ctypes.c_float), ("half_box", ctypes.c_float * 3),
+                ("step", ctypes.c_double)]
+
+
 # name -> (restype, argtypes); mirrors include/mdx.h one to one
 SIGNATURES = {
     "mdx_version": (ctypes.c_int, []),
@@ -88,6 +99,8 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int64, c_i64_p,
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "mdx_rdf_read": (ctypes.c_int, [ctypes.c_void_p, c_u64_p]),
+    "mdx_rdf_fast_plan": (ctypes.c_int, [c_f32_p, ctypes.c_float, ctypes.c_int,
+                                         ctypes.POINTER(RdfFastPlan)]),
     "mdx_comm_available": (ctypes.c_int, []),
     "mdx_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
     "mdx_comm_create": (ctypes.c_int, [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,

@@ -544,7 +544,24 @@ __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
   const uint32_t frac_mask = in_vgpr(p.fast_frac_mask);
   const uint32_t one = in_vgpr(1u);
 
+  // Adds the block's LDS counts of `key` to the device histogram and clears them.
+  auto flush = [&](int key) {
+    unsigned long long *out = g_hist + static_cast<int64_t>(key) * p.nbins;
+    for (int b = tid; b < lds_hist_words; b += kTile) {
+      const uint32_t v = hist[b];
+      if (v != 0u && b < p.nbins) atomicAdd(&out[b], static_cast<unsigned long long>(v));
+      hist[b] = 0u;
+    }
+    __syncthreads();
+  };
+
   int cur_key = -1;
+  // pairs counted into the LDS bins since they were last cleared: a bin is a uint32, and
+  // nothing bounds how many pairs of a block share one bin (coincident atoms, one shell),
+  // so the bins are flushed before the count could pass 2^32
+  unsigned long long since_flush = 0ull;
+  const unsigned long long chunk_pairs_max =
+      static_cast<unsigned long long>(frames_per_chunk) * kTile * kTile;
   for (int turn = 0; turn < kWorkLists; ++turn) {
     const int list = (static_cast<int>(blockIdx.x) + turn) % kWorkLists;
     // frame groups list, list + 8, ...: how many, and the list's chunk count
@@ -567,19 +584,17 @@ __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
           static_cast<int>(local - turn_in_list * static_cast<uint32_t>(in_key.key_pairs));
       const int group = list + kWorkLists * static_cast<int>(turn_in_list);
       const TilePair tp = pairs[pair_index];
-      if (tp.key != cur_key) {
+      if (tp.key != cur_key || since_flush + chunk_pairs_max > 0xFFFFFFFFull) {
         if (cur_key >= 0) {
-          unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
-          for (int b = tid; b < p.nbins; b += kTile) {
-            const uint32_t v = hist[b];
-            if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
-          }
+          flush(cur_key);
+        } else {
+          for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
           __syncthreads();
         }
-        for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
-        __syncthreads();
         cur_key = tp.key;
+        since_flush = 0ull;
       }
+      since_flush += chunk_pairs_max;
       const int f_begin = group * frames_per_chunk;
       const int f_end = min(n_frames, f_begin + frames_per_chunk);
       const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
@@ -602,13 +617,7 @@ __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
       __syncthreads();  // the chunk's counts are in before a flush or the next claim
     }
   }
-  if (cur_key >= 0) {
-    unsigned long long *out = g_hist + static_cast<int64_t>(cur_key) * p.nbins;
-    for (int b = tid; b < p.nbins; b += kTile) {
-      const uint32_t v = hist[b];
-      if (v != 0u) atomicAdd(&out[b], static_cast<unsigned long long>(v));
-    }
-  }
+  if (cur_key >= 0) flush(cur_key);
 }
 
 // ---------------------------------------------------------------- tile kernel
@@ -811,6 +820,39 @@ void rdf_fast_setup(RdfParams &p) {
   p.fast_ok = 1;
 }
 
+// Everything of RdfParams that follows from the geometry alone (no device needed).
+void rdf_host_params(RdfParams &p, const float box[3], float cutoff, int nbins) {
+  for (int c = 0; c < 3; ++c) {
+    p.box[c] = box[c];
+    p.inv_box[c] = 1.0f / box[c];
+  }
+  p.cutoff = cutoff;
+  p.nbins = nbins;
+  // tf.histogram_fixed_width: step = double(range[1] - range[0]) / double(nbins),
+  // with the subtraction done in float32.
+  const float width = cutoff - 0.0f;
+  p.step = static_cast<double>(width) / static_cast<double>(nbins);
+  p.inv_step = static_cast<float>(static_cast<double>(nbins) / static_cast<double>(width));
+  // |approximate - exact bin position| <= position * (1 ulp sqrt + 2 roundings), kept
+  // below position * 2^-21; positions never exceed nbins (+1).
+  {
+    double eps = (static_cast<double>(nbins) + 2.0) * 0x1p-21 + 0x1p-20;
+    if (eps > 0.25) eps = 0.5;  // then every pair consults the thresholds
+    p.edge_eps = static_cast<float>(eps);
+    p.edge_eps2 = static_cast<float>(2.0 * eps);
+  }
+  for (int c = 0; c < 3; ++c) {
+    p.t_wrap[c] = first_a_reaching(1.0f, box[c]);
+    p.t_far[c] = first_a_reaching(2.0f, box[c]);
+    // The wrapped-frame path takes min(|r|, L - |r|), which equals the literal
+    // result only if no float lies strictly between L/2 and t_wrap (always the case
+    // for IEEE float32; checked anyway).  Otherwise no frame may use that path.
+    if (p.t_wrap[c] != nextafterf(box[c] * 0.5f, INFINITY)) p.t_far[c] = 0.0f;
+  }
+  rdf_fast_setup(p);
+  p.s_cut = first_s_reaching(nbins, cutoff, p.step, nbins);
+}
+
 }  // namespace
 
 struct mdx_rdf_s {
@@ -917,6 +959,8 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
       const int v = atoi(env);
       if (v >= 1) frames_per_chunk = v;
     }
+    // a chunk's pairs must fit the kernel's uint32 LDS bins with room to spare
+    if (frames_per_chunk > 16384) frames_per_chunk = 16384;
     const int64_t n_groups = ceil_div(nf, frames_per_chunk);
     const int64_t n_chunks = n_groups * h->n_pairs_shard;
     MDX_REQUIRE(n_chunks + h->fast_blocks < (int64_t(1) << 31), "too many work chunks");
@@ -1125,33 +1169,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   h->flags = flags;
   h->n_per_species.assign(n_per_species, n_per_species + n_species);
   RdfParams &p = h->params;
-  for (int c = 0; c < 3; ++c) {
-    p.box[c] = box[c];
-    p.inv_box[c] = 1.0f / box[c];
-  }
-  p.cutoff = cutoff;
-  p.nbins = nbins;
-  // tf.histogram_fixed_width: step = double(range[1] - range[0]) / double(nbins),
-  // with the subtraction done in float32.
-  const float width = cutoff - 0.0f;
-  p.step = static_cast<double>(width) / static_cast<double>(nbins);
-  p.inv_step = static_cast<float>(static_cast<double>(nbins) / static_cast<double>(width));
-  // |approximate - exact bin position| <= position * (1 ulp sqrt + 2 roundings), kept
-  // below position * 2^-21; positions never exceed nbins (+1).
-  {
-    double eps = (static_cast<double>(nbins) + 2.0) * 0x1p-21 + 0x1p-20;
-    if (eps > 0.25) eps = 0.5;  // then every pair consults the thresholds
-    p.edge_eps = static_cast<float>(eps);
-    p.edge_eps2 = static_cast<float>(2.0 * eps);
-  }
-  for (int c = 0; c < 3; ++c) {
-    p.t_wrap[c] = first_a_reaching(1.0f, box[c]);
-    p.t_far[c] = first_a_reaching(2.0f, box[c]);
-    // The wrapped-frame path takes min(|r|, L - |r|), which equals the literal
-    // result only if no float lies strictly between L/2 and t_wrap (always the case
-    // for IEEE float32; checked anyway).  Otherwise no frame may use that path.
-    if (p.t_wrap[c] != nextafterf(box[c] * 0.5f, INFINITY)) p.t_far[c] = 0.0f;
-  }
+  rdf_host_params(p, box, cutoff, nbins);
 
   // slots: per species, the atoms that take part, padded to whole tiles
   const bool strict = (flags & MDX_RDF_STRICT_REFERENCE_MASKS) != 0u;
@@ -1226,7 +1244,6 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
                                 static_cast<int>(h->lds_bytes)));
   }
 
-  rdf_fast_setup(p);
   if (!literal && p.fast_ok) {
     h->fast_lds_hist_words = (nbins + 1 + 3) & ~3;
     h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
@@ -1244,7 +1261,10 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
       hipDeviceProp_t prop;
       MDX_HIP(hipGetDeviceProperties(&prop, h->device));
       h->fast_blocks = per_cu * prop.multiProcessorCount;
-      if (getenv("MDX_RDF_FAST_NO_EDGE")) p.fast_edge_units = 0;  // timing experiments only
+#ifdef MDX_TIMING_SWITCHES
+      // builds for timing experiments only: without the near-edge test the counts are wrong
+      if (getenv("MDX_RDF_FAST_NO_EDGE")) p.fast_edge_units = 0;
+#endif
       if (getenv("MDX_RDF_DEBUG"))
         fprintf(stderr, "rdf fast: %d blocks/CU, %d CUs, lds %zu, edge units %u of %u\n", per_cu,
                 prop.multiProcessorCount, h->fast_lds_bytes, p.fast_edge_units,
@@ -1275,8 +1295,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   }
   MDX_TRY(h->d_species_ptr.alloc(sizeof(void *) * n_species));
 
-  // thresholds of the table kernel (also defines s_cut)
-  p.s_cut = first_s_reaching(nbins, cutoff, p.step, nbins);
+  // thresholds of the table kernel
   if (!literal) {
     std::vector<float> thr(static_cast<size_t>(nbins) + 1);
     thr[0] = 0.0f;
@@ -1290,6 +1309,29 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 
   guard.h = nullptr;
   *handle = h;
+  return MDX_OK;
+}
+
+int mdx_rdf_fast_plan(const float box[3], float cutoff, int nbins, mdx_rdf_fast_plan_t *plan) {
+  MDX_REQUIRE(box != nullptr && plan != nullptr, "null argument");
+  MDX_REQUIRE(nbins >= 1, "nbins must be positive");
+  MDX_REQUIRE(cutoff > 0.0f && std::isfinite(cutoff), "cutoff must be positive and finite");
+  for (int c = 0; c < 3; ++c)
+    MDX_REQUIRE(box[c] > 0.0f && std::isfinite(box[c]), "box lengths must be positive");
+  RdfParams p{};
+  rdf_host_params(p, box, cutoff, nbins);
+  memset(plan, 0, sizeof(*plan));
+  plan->usable = p.fast_ok;
+  plan->step = p.step;
+  plan->scale = p.inv_step;
+  plan->s_cut = p.s_cut;
+  for (int c = 0; c < 3; ++c) plan->half_box[c] = p.half_box[c];
+  if (p.fast_ok) {
+    plan->frac_bits = static_cast<int>(p.fast_frac_bits);
+    plan->edge_units = p.fast_edge_units;
+    plan->keep_bits = p.fast_keep_bits;
+    plan->magic = p.fast_magic;
+  }
   return MDX_OK;
 }
 

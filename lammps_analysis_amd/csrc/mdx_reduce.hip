@@ -10,6 +10,13 @@
 // partial sums are combined by a second kernel in chunk order, so results do not
 // depend on scheduling.
 //
+// The flux reductions combine arrays of different row widths per (atom, frame): stress
+// [6], velocity [3], energies [1].  A lane that owned one frame would read 4-byte pieces
+// 24 and 12 bytes apart; flux_stream_kernel instead has every wave fetch its 128 frames
+// of each array with lane-contiguous 16- and 8-byte loads, passes the stress and the
+// vector through a wave-private LDS image, and only then lets lane l pick up the two
+// frames 2l, 2l+1 it accumulates.
+//
 // Compiled with -ffp-contract=off: products are rounded before they are added,
 // as in the reference's separate multiply and reduce_sum operations.
 #include "mdx_common.h"
@@ -48,10 +55,14 @@ struct VecLoad<T, 1> {
 };
 
 // partial[chunk][col] = sum over the chunk's atoms of w_a * x[a][col]
-template <typename T, int VEC>
+// kPick: only the components c >= pick_first of every group of pick_k columns are
+// written, packed as [group][c - pick_first] (the momentum flux keeps components 3..5 of
+// the six stress components; the whole 24-byte rows are fetched either way, the halves
+// share their 64-byte sectors).
+template <typename T, int VEC, bool kPick>
 __global__ __launch_bounds__(kThreads) void weighted_sum_kernel(
     const T *__restrict__ x, const double *__restrict__ weights, double scalar,
-    int64_t n_atoms, int64_t row_len, int64_t atoms_per_chunk,
+    int64_t n_atoms, int64_t row_len, int64_t atoms_per_chunk, int pick_k, int pick_first,
     double *__restrict__ partial) {
   const int64_t col = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * VEC;
   if (col >= row_len) return;
@@ -82,40 +93,163 @@ __global__ __launch_bounds__(kThreads) void weighted_sum_kernel(
     for (int v = 0; v < VEC; ++v) acc[v] = acc[v] + w * vals[v];
     p += row_len;
   }
-  double *dst = partial + static_cast<int64_t>(blockIdx.y) * row_len + col;
+  if (!kPick) {
+    double *dst = partial + static_cast<int64_t>(blockIdx.y) * row_len + col;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) dst[v] = acc[v];
+    for (int v = 0; v < VEC; ++v) dst[v] = acc[v];
+  } else {
+    const int kept = pick_k - pick_first;
+    double *dst = partial + static_cast<int64_t>(blockIdx.y) * (row_len / pick_k) * kept;
+    const int64_t group = col / pick_k;
+    int c = static_cast<int>(col - group * pick_k);
+    int64_t base = group * kept;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (c >= pick_first) dst[base + c - pick_first] = acc[v];
+      if (++c == pick_k) {
+        c = 0;
+        base += kept;
+      }
+    }
+  }
 }
 
-// partial[chunk][t*3+c] = sum over the chunk's atoms of stress[a][t][3+c]
-template <typename T>
-__global__ __launch_bounds__(kThreads) void momentum_flux_kernel(
-    const T *__restrict__ stress, int64_t n_atoms, int64_t n_frames,
-    int64_t atoms_per_chunk, double *__restrict__ partial) {
-  const int64_t col = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  const int64_t n_cols = n_frames * 3;
-  if (col >= n_cols) return;
-  const int64_t t = col / 3;
-  const int c = static_cast<int>(col - t * 3);
+// Streaming flux reductions of float32 arrays with an even number of frames.
+//   kThermal: partial[chunk][0][t*3+c] = sum_a (ke+pe) * v_c,
+//             partial[chunk][1][t*3+c] = sum_a phi_c, phi = S . v for the symmetric stress
+//             stored as xx,yy,zz,xy,xz,yz (six = stress, three = velocities);
+//   else    : partial[chunk][t*3+c] = sum_a x_c * (ke+pe)   (three = x, six unused).
+// Wave = 128 consecutive frames, walking down the chunk's atoms.  Per atom the wave's
+// slice of every array is one contiguous range: 3072 B of stress (three 16-byte loads
+// per lane), 1536 B of the vector (three 8-byte loads), 512 B of each energy (one 8-byte
+// load, already the lane's own two frames).  Stress and vector are copied as they come
+// into the wave's LDS image; lane l then reads words 12l..12l+11 and 6l..6l+5 (8-byte
+// reads 12 and 6 words apart: sixteen lanes hit disjoint banks).  Only lanes of one wave
+// exchange data, and a wave's LDS operations complete in order, so no barrier is needed.
+// The next atom's loads are in flight while the current one is summed.  Every element
+// is read once: non-temporal loads.
+constexpr int kWaveFrames = 128;
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <bool kThermal>
+__global__ __launch_bounds__(kThreads) void flux_stream_kernel(
+    const float *__restrict__ six, const float *__restrict__ three,
+    const float *__restrict__ ke, const float *__restrict__ pe, int64_t n_atoms,
+    int64_t n_frames, int64_t atoms_per_chunk, double *__restrict__ partial) {
+  constexpr int kSixWords = kThermal ? kWaveFrames * 6 : 0;
+  constexpr int kWaves = kThreads / 64;
+  __shared__ __align__(16) float image[kWaves][kSixWords + kWaveFrames * 3];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t t0 = (static_cast<int64_t>(blockIdx.x) * kWaves + wave) * kWaveFrames;
+  if (t0 >= n_frames) return;  // no block-wide synchronisation below
+  const int frames_here = static_cast<int>(min<int64_t>(kWaveFrames, n_frames - t0));  // even
+  const int six_units = frames_here * 6 / 4;   // 16-byte units of the stress slice
+  const int three_units = frames_here * 3 / 2; // 8-byte units of the vector slice
+  const int pair_units = frames_here / 2;      // 8-byte units of an energy slice
   const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
   const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
-  const int64_t row_len = n_frames * 6;
-  const T *p = stress + a0 * row_len + t * 6 + 3 + c;
-  double acc = 0.0;
-  int64_t a = a0;
-  for (; a + kUnroll <= a1; a += kUnroll) {
-    double vals[kUnroll];
+  float *my_six = image[wave];
+  float *my_three = image[wave] + kSixWords;
+
+  f4v s_next[3];
+  f2v v_next[3], k_next, p_next;
+  // Units past the slice's end (last tile of the frame axis) re-read the slice's last unit
+  // and are replaced by zero where the values are used (not here: a select right behind
+  // the load would make the wave wait for it): no branch around a load.
+  auto fetch = [&](int64_t a) {
+    const int64_t at = a * n_frames + t0;
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) vals[u] = static_cast<double>(p[u * row_len]);
+    for (int j = 0; j < 3; ++j) {
+      const int u = lane + 64 * j;
+      if (kThermal)
+        s_next[j] = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(six + at * 6) +
+                                               min(u, six_units - 1));
+      v_next[j] = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(three + at * 3) +
+                                             min(u, three_units - 1));
+    }
+    const int own = min(lane, pair_units - 1);
+    k_next = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(ke + at) + own);
+    p_next = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(pe + at) + own);
+  };
+
+  double ev[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  double ph[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  if (a0 < a1) fetch(a0);
+  for (int64_t a = a0; a < a1; ++a) {
+    f4v s_cur[3];
+    f2v v_cur[3];
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) acc = acc + vals[u];
-    p += kUnroll * row_len;
+    for (int j = 0; j < 3; ++j) {
+      const int u = lane + 64 * j;
+      if (kThermal) s_cur[j] = u < six_units ? s_next[j] : f4v{0.f, 0.f, 0.f, 0.f};
+      v_cur[j] = u < three_units ? v_next[j] : f2v{0.f, 0.f};
+    }
+    const f2v k_cur = lane < pair_units ? k_next : f2v{0.f, 0.f};
+    const f2v p_cur = lane < pair_units ? p_next : f2v{0.f, 0.f};
+    if (a + 1 < a1) fetch(a + 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (kThermal) *reinterpret_cast<f4v *>(my_six + 4 * (lane + 64 * j)) = s_cur[j];
+      *reinterpret_cast<f2v *>(my_three + 2 * (lane + 64 * j)) = v_cur[j];
+    }
+    // the wave's own writes are visible to its later reads; keep the compiler from
+    // moving the reads of other lanes' words above them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float sw[12], vw[6];
+    if (kThermal) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const f2v t = *reinterpret_cast<const f2v *>(my_six + 12 * lane + 2 * j);
+        sw[2 * j] = t.x;
+        sw[2 * j + 1] = t.y;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f2v t = *reinterpret_cast<const f2v *>(my_three + 6 * lane + 2 * j);
+      vw[2 * j] = t.x;
+      vw[2 * j + 1] = t.y;
+    }
+    // reads done before the next atom's image overwrites them (program order within the
+    // wave; the fence keeps the compiler from sinking the reads)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      double v[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) v[i] = static_cast<double>(vw[3 * f + i]);
+      const double e = static_cast<double>(f == 0 ? k_cur.x : k_cur.y) +
+                       static_cast<double>(f == 0 ? p_cur.x : p_cur.y);
+      if (kThermal) {
+        double s[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s[i] = static_cast<double>(sw[6 * f + i]);
+        ph[f][0] = ph[f][0] + ((s[0] * v[0] + s[3] * v[1]) + s[4] * v[2]);
+        ph[f][1] = ph[f][1] + ((s[3] * v[0] + s[1] * v[1]) + s[5] * v[2]);
+        ph[f][2] = ph[f][2] + ((s[4] * v[0] + s[5] * v[1]) + s[2] * v[2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ev[f][i] = ev[f][i] + e * v[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ev[f][i] = ev[f][i] + v[i] * e;
+      }
+    }
   }
-  for (; a < a1; ++a) {
-    acc = acc + static_cast<double>(*p);
-    p += row_len;
-  }
-  partial[static_cast<int64_t>(blockIdx.y) * n_cols + col] = acc;
+  if (lane >= pair_units) return;
+  const int64_t n_cols = n_frames * 3;
+  double *dst = partial + static_cast<int64_t>(blockIdx.y) * (kThermal ? 2 : 1) * n_cols +
+                (t0 + 2 * lane) * 3;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dst[3 * f + i] = ev[f][i];
+      if (kThermal) dst[n_cols + 3 * f + i] = ph[f][i];
+    }
 }
 
 // partial[chunk][0][t*3+c] = sum_a (ke+pe) * v_c ; partial[chunk][1][t*3+c] = sum_a phi_c
@@ -393,6 +527,65 @@ int zero_result(double *out, int out_location, int64_t n_cols, int accumulate,
   return MDX_OK;
 }
 
+// Launches the weighted column sum (all columns, or the picked components of every group
+// of pick_k columns when pick_k > 0) of x [n_atoms][row_len] into partial[chunk][...].
+// `fit_chunks` > 0 caps the number of atom chunks (a caller with a fixed scratch array).
+int launch_column_sum(const void *x, int dtype, const double *weights, double scalar,
+                      int64_t n_atoms, int64_t row_len, int pick_k, int pick_first,
+                      int64_t fit_chunks, double *partial_fixed, DeviceBuffer *partial,
+                      ChunkPlan *plan_out, hipStream_t stream) {
+  const int width = (dtype == MDX_F32) ? 4 : 2;
+  const bool wide = (row_len % width == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+  const int64_t threads_needed = wide ? row_len / width : row_len;
+  ChunkPlan plan = plan_chunks(n_atoms, threads_needed);
+  if (fit_chunks > 0 && plan.n_chunks > fit_chunks) {
+    plan.atoms_per_chunk = ceil_div(n_atoms, fit_chunks);
+    plan.n_chunks = ceil_div(n_atoms, plan.atoms_per_chunk);
+  }
+  const int64_t out_cols = pick_k > 0 ? (row_len / pick_k) * (pick_k - pick_first) : row_len;
+  double *dst = partial_fixed;
+  if (dst == nullptr) {
+    MDX_TRY(partial->alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * out_cols));
+    dst = partial->as<double>();
+  }
+  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+#define MDX_COLUMN_SUM(TYPE, VEC, PICK)                                                     \
+  hipLaunchKernelGGL((weighted_sum_kernel<TYPE, VEC, PICK>), grid, dim3(kThreads), 0,       \
+                     stream, static_cast<const TYPE *>(x), weights, scalar, n_atoms,        \
+                     row_len, plan.atoms_per_chunk, pick_k, pick_first, dst)
+  if (dtype == MDX_F32) {
+    if (wide) {
+      if (pick_k > 0) MDX_COLUMN_SUM(float, 4, true); else MDX_COLUMN_SUM(float, 4, false);
+    } else {
+      if (pick_k > 0) MDX_COLUMN_SUM(float, 1, true); else MDX_COLUMN_SUM(float, 1, false);
+    }
+  } else {
+    if (wide) {
+      if (pick_k > 0) MDX_COLUMN_SUM(double, 2, true); else MDX_COLUMN_SUM(double, 2, false);
+    } else {
+      if (pick_k > 0) MDX_COLUMN_SUM(double, 1, true); else MDX_COLUMN_SUM(double, 1, false);
+    }
+  }
+#undef MDX_COLUMN_SUM
+  MDX_HIP(hipGetLastError());
+  *plan_out = plan;
+  return MDX_OK;
+}
+
+// True when the streaming flux kernel applies: float32, an even number of frames (every
+// row then starts on the load width of its array) and 16-byte aligned arrays.
+bool stream_layout_ok(int dtype, int64_t n_frames, std::initializer_list<const void *> arrays) {
+  if (dtype != MDX_F32 || (n_frames & 1) != 0) return false;
+  for (const void *p : arrays)
+    if (reinterpret_cast<uintptr_t>(p) % 16 != 0) return false;
+  return true;
+}
+
+ChunkPlan plan_stream_chunks(int64_t n_atoms, int64_t n_frames) {
+  // one wave per 128 frames, four waves per block
+  return plan_chunks(n_atoms, ceil_div(n_frames, kWaveFrames) * 64);
+}
+
 }  // namespace
 
 extern "C" {
@@ -419,37 +612,12 @@ int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_at
                            hipMemcpyHostToDevice, stream));
     dw = w_dev.as<double>();
   }
-  const int vec = (dtype == MDX_F32) ? 4 : 2;
-  const bool aligned = (row_len % vec == 0) && (reinterpret_cast<uintptr_t>(dx) % 16 == 0);
-  const int64_t threads_needed = aligned ? row_len / vec : row_len;
-  const ChunkPlan plan = plan_chunks(n_atoms, threads_needed);
-  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * row_len));
-  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
+  ChunkPlan plan;
   {
-  KernelTimer timer(MDX_SLOT_ATOM_SUM, stream);
-  if (dtype == MDX_F32) {
-    const float *xf = static_cast<const float *>(dx);
-    if (aligned)
-      hipLaunchKernelGGL((weighted_sum_kernel<float, 4>), grid, dim3(kThreads), 0, stream, xf,
-                         dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial.as<double>());
-    else
-      hipLaunchKernelGGL((weighted_sum_kernel<float, 1>), grid, dim3(kThreads), 0, stream, xf,
-                         dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial.as<double>());
-  } else {
-    const double *xd = static_cast<const double *>(dx);
-    if (aligned)
-      hipLaunchKernelGGL((weighted_sum_kernel<double, 2>), grid, dim3(kThreads), 0, stream,
-                         xd, dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial.as<double>());
-    else
-      hipLaunchKernelGGL((weighted_sum_kernel<double, 1>), grid, dim3(kThreads), 0, stream,
-                         xd, dw, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial.as<double>());
+    KernelTimer timer(MDX_SLOT_ATOM_SUM, stream);
+    MDX_TRY(launch_column_sum(dx, dtype, dw, scalar_weight, n_atoms, row_len, 0, 0, 0, nullptr,
+                              &partial, &plan, stream));
   }
-  }
-  MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, row_len, out, out_location,
                  accumulate, stream));
   // scoped device buffers are released on return
@@ -474,39 +642,9 @@ int mdx_weighted_atom_sum_static(const void *x, int dtype, int64_t n_atoms, int6
   MDX_TRY(scratch_address(&partial));
   if (n_atoms == 0 || row_len == 0) return zero_result(out, MDX_DEVICE, row_len, accumulate, stream);
 
-  const int vec = (dtype == MDX_F32) ? 4 : 2;
-  const bool aligned = (row_len % vec == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-  const int64_t threads_needed = aligned ? row_len / vec : row_len;
-  ChunkPlan plan = plan_chunks(n_atoms, threads_needed);
-  const int64_t fit = kScratchDoubles / row_len;  // >= 1
-  if (plan.n_chunks > fit) {
-    plan.atoms_per_chunk = ceil_div(n_atoms, fit);
-    plan.n_chunks = ceil_div(n_atoms, plan.atoms_per_chunk);
-  }
-  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
-  const double *no_weights = nullptr;
-  if (dtype == MDX_F32) {
-    const float *xf = static_cast<const float *>(x);
-    if (aligned)
-      hipLaunchKernelGGL((weighted_sum_kernel<float, 4>), grid, dim3(kThreads), 0, stream, xf,
-                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial);
-    else
-      hipLaunchKernelGGL((weighted_sum_kernel<float, 1>), grid, dim3(kThreads), 0, stream, xf,
-                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial);
-  } else {
-    const double *xd = static_cast<const double *>(x);
-    if (aligned)
-      hipLaunchKernelGGL((weighted_sum_kernel<double, 2>), grid, dim3(kThreads), 0, stream, xd,
-                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial);
-    else
-      hipLaunchKernelGGL((weighted_sum_kernel<double, 1>), grid, dim3(kThreads), 0, stream, xd,
-                         no_weights, scalar_weight, n_atoms, row_len, plan.atoms_per_chunk,
-                         partial);
-  }
-  MDX_HIP(hipGetLastError());
+  ChunkPlan plan;
+  MDX_TRY(launch_column_sum(x, dtype, nullptr, scalar_weight, n_atoms, row_len, 0, 0,
+                            kScratchDoubles / row_len, partial, nullptr, &plan, stream));
   hipLaunchKernelGGL(combine_chunks_kernel,
                      dim3(static_cast<unsigned>(ceil_div(row_len, kThreads))), dim3(kThreads), 0,
                      stream, partial, static_cast<int>(plan.n_chunks), 1, row_len, out,
@@ -527,18 +665,13 @@ int mdx_momentum_flux(const void *stress, int dtype, int location, int64_t n_ato
   MDX_TRY(to_device(stress, location,
                     static_cast<size_t>(n_atoms) * n_frames * 6 * dtype_size(dtype), staged,
                     stream, &ds));
-  const ChunkPlan plan = plan_chunks(n_atoms, n_cols);
-  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
-  dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
-  if (dtype == MDX_F32)
-    hipLaunchKernelGGL(momentum_flux_kernel<float>, grid, dim3(kThreads), 0, stream,
-                       static_cast<const float *>(ds), n_atoms, n_frames,
-                       plan.atoms_per_chunk, partial.as<double>());
-  else
-    hipLaunchKernelGGL(momentum_flux_kernel<double>, grid, dim3(kThreads), 0, stream,
-                       static_cast<const double *>(ds), n_atoms, n_frames,
-                       plan.atoms_per_chunk, partial.as<double>());
-  MDX_HIP(hipGetLastError());
+  // the column sum of the [n_frames][6] rows, of which components 3..5 are kept
+  ChunkPlan plan;
+  {
+    KernelTimer timer(MDX_SLOT_FLUX, stream);
+    MDX_TRY(launch_column_sum(ds, dtype, nullptr, 1.0, n_atoms, n_frames * 6, 6, 3, 0, nullptr,
+                              &partial, &plan, stream));
+  }
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,
                  accumulate, stream));
   MDX_HIP(hipStreamSynchronize(stream));
@@ -561,10 +694,19 @@ int mdx_thermal_flux(const void *stress, const void *vel, const void *ke, const 
   MDX_TRY(to_device(vel, location, unit * 3, st_v, stream, &dv));
   MDX_TRY(to_device(ke, location, unit, st_k, stream, &dk));
   MDX_TRY(to_device(pe, location, unit, st_p, stream, &dp));
-  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
+  const bool streamed = stream_layout_ok(dtype, n_frames, {ds, dv, dk, dp});
+  const ChunkPlan plan =
+      streamed ? plan_stream_chunks(n_atoms, n_frames) : plan_chunks(n_atoms, n_frames);
   MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * 2 * n_cols));
   dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
-  if (dtype == MDX_F32)
+  {
+  KernelTimer timer(MDX_SLOT_FLUX, stream);
+  if (streamed)
+    hipLaunchKernelGGL(flux_stream_kernel<true>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const float *>(ds), static_cast<const float *>(dv),
+                       static_cast<const float *>(dk), static_cast<const float *>(dp),
+                       n_atoms, n_frames, plan.atoms_per_chunk, partial.as<double>());
+  else if (dtype == MDX_F32)
     hipLaunchKernelGGL(thermal_flux_kernel<float>, grid, dim3(kThreads), 0, stream,
                        static_cast<const float *>(ds), static_cast<const float *>(dv),
                        static_cast<const float *>(dk), static_cast<const float *>(dp),
@@ -574,6 +716,7 @@ int mdx_thermal_flux(const void *stress, const void *vel, const void *ke, const 
                        static_cast<const double *>(ds), static_cast<const double *>(dv),
                        static_cast<const double *>(dk), static_cast<const double *>(dp),
                        n_atoms, n_frames, plan.atoms_per_chunk, partial.as<double>());
+  }
   MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 2, n_cols, out, out_location,
                  accumulate, stream));
@@ -596,10 +739,19 @@ int mdx_energy_weighted_sum(const void *x, const void *ke, const void *pe, int d
   MDX_TRY(to_device(x, location, unit * 3, st_x, stream, &dx));
   MDX_TRY(to_device(ke, location, unit, st_k, stream, &dk));
   MDX_TRY(to_device(pe, location, unit, st_p, stream, &dp));
-  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
+  const bool streamed = stream_layout_ok(dtype, n_frames, {dx, dk, dp});
+  const ChunkPlan plan =
+      streamed ? plan_stream_chunks(n_atoms, n_frames) : plan_chunks(n_atoms, n_frames);
   MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
   dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
-  if (dtype == MDX_F32)
+  {
+  KernelTimer timer(MDX_SLOT_FLUX, stream);
+  if (streamed)
+    hipLaunchKernelGGL(flux_stream_kernel<false>, grid, dim3(kThreads), 0, stream,
+                       static_cast<const float *>(nullptr), static_cast<const float *>(dx),
+                       static_cast<const float *>(dk), static_cast<const float *>(dp),
+                       n_atoms, n_frames, plan.atoms_per_chunk, partial.as<double>());
+  else if (dtype == MDX_F32)
     hipLaunchKernelGGL(energy_weighted_kernel<float>, grid, dim3(kThreads), 0, stream,
                        static_cast<const float *>(dx), static_cast<const float *>(dk),
                        static_cast<const float *>(dp), n_atoms, n_frames,
@@ -609,6 +761,7 @@ int mdx_energy_weighted_sum(const void *x, const void *ke, const void *pe, int d
                        static_cast<const double *>(dx), static_cast<const double *>(dk),
                        static_cast<const double *>(dp), n_atoms, n_frames,
                        plan.atoms_per_chunk, partial.as<double>());
+  }
   MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,
                  accumulate, stream));

@@ -24,14 +24,29 @@ the ranks of one node itself.
 
 File writes: every rank runs the same script against the same project directory, so
 only rank 0 (``is_writer()``) writes; ``run_on_writer`` makes the others wait.
+
+Trust: the host channel carries pickled Python objects, so both ends of a connection
+prove who they are before the first object is read.  On a ``unix:`` address the kernel
+reports the peer's user id (``SO_PEERCRED``) and it must be this process's own; on a
+``tcp:`` address both ends answer an HMAC-SHA256 challenge keyed with ``MDX_COMM_TOKEN``
+(``launch()`` exports a random one; without a token a ``tcp:`` rendezvous is refused).
+The first message of a connection is a fixed-size binary record, never a pickle.
+
+No silent downgrade: when every rank drives a GPU of its own the sums go through RCCL, and
+a communicator that cannot be created is an error (``RuntimeError`` on every rank) unless
+the host transport was asked for by name (``MDX_COMM_TRANSPORT=host``).  Ranks that share
+a GPU or have none (tests) use the host transport; RCCL cannot serve them.
 """
 from __future__ import annotations
 
 import atexit
 import ctypes
+import hashlib
+import hmac
 import logging
 import os
 import pickle
+import secrets
 import socket
 import struct
 import subprocess
@@ -80,6 +95,50 @@ def _parse_address(address: str):
     raise ValueError(f"bad rendezvous address '{address}' (unix:<name> or tcp:<host>:<port>)")
 
 
+_HELLO = struct.Struct("<4sII")   # magic, rank, world size
+_MAGIC = b"MDX1"
+_NONCE_BYTES = 32
+
+
+def _peer_uid(conn: socket.socket) -> int:
+    """User id of the process at the other end of a unix-domain connection."""
+    creds = conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+    _pid, uid, _gid = struct.unpack("3i", creds)
+    return uid
+
+
+def _token() -> Optional[bytes]:
+    value = os.environ.get("MDX_COMM_TOKEN")
+    return value.encode() if value else None
+
+
+def _answer(token: bytes, nonce: bytes, role: bytes) -> bytes:
+    return hmac.new(token, role + nonce, hashlib.sha256).digest()
+
+
+def _authenticate(conn: socket.socket, family: int, serving: bool) -> None:
+    """Both ends prove their identity before any pickled object crosses the connection
+    (see the module docstring).  Raises PermissionError."""
+    if family == socket.AF_UNIX:
+        uid = _peer_uid(conn)
+        if uid != os.getuid():
+            raise PermissionError(f"rendezvous peer runs as uid {uid}, not {os.getuid()}")
+        return
+    token = _token()
+    if token is None:
+        raise PermissionError("a tcp: rendezvous needs MDX_COMM_TOKEN (the same secret on "
+                              "every rank); parallel.launch() sets one")
+    mine = secrets.token_bytes(_NONCE_BYTES)
+    conn.sendall(mine)
+    theirs = _recv_exact(conn, _NONCE_BYTES)
+    # each side answers the other's nonce, tagged with its own role, so an answer cannot
+    # be reflected back to its author
+    conn.sendall(_answer(token, theirs, b"S" if serving else b"C"))
+    proof = _recv_exact(conn, hashlib.sha256().digest_size)
+    if not hmac.compare_digest(proof, _answer(token, mine, b"C" if serving else b"S")):
+        raise PermissionError("rendezvous peer does not hold MDX_COMM_TOKEN")
+
+
 class HostChannel:
     """Star over stream sockets: rank 0 serves, ranks 1..n-1 each hold one connection."""
 
@@ -90,44 +149,74 @@ class HostChannel:
         self._server = None
         if size == 1:
             return
-        if rank == 0:
-            server = socket.socket(family, socket.SOCK_STREAM)
-            if family == socket.AF_INET:
-                server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            server.bind(target)
-            server.listen(size)
-            server.settimeout(_CONNECT_TIMEOUT_S)
-            self._server = server
-            for _ in range(size - 1):
-                try:
-                    conn, _addr = server.accept()
-                except socket.timeout:
-                    raise TimeoutError(f"rank 0 waited {_CONNECT_TIMEOUT_S:.0f} s for "
-                                       f"{size - 1} rank(s) at {address}") from None
-                conn.settimeout(None)
-                if family == socket.AF_INET:
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                peer = pickle.loads(_recv_msg(conn))
-                if not (0 < peer < size) or self._peers[peer] is not None:
-                    raise RuntimeError(f"unexpected rank {peer} at the rendezvous")
-                self._peers[peer] = conn
-        else:
-            deadline = time.monotonic() + _CONNECT_TIMEOUT_S
-            while True:
-                conn = socket.socket(family, socket.SOCK_STREAM)
-                try:
-                    conn.connect(target)
-                    break
-                except (ConnectionRefusedError, FileNotFoundError, OSError):
-                    conn.close()
-                    if time.monotonic() > deadline:
-                        raise TimeoutError(f"rank {rank} could not reach rank 0 at "
-                                           f"{address}") from None
-                    time.sleep(0.05)
+        try:
+            if rank == 0:
+                self._serve(family, target)
+            else:
+                self._join(family, target)
+        except BaseException:
+            self.close()
+            raise
+
+    def _serve(self, family, target) -> None:
+        size, address = self.size, self.address
+        server = socket.socket(family, socket.SOCK_STREAM)
+        self._server = server
+        if family == socket.AF_INET:
+            server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        server.bind(target)
+        server.listen(size)
+        deadline = time.monotonic() + _CONNECT_TIMEOUT_S
+        joined = 0
+        while joined < size - 1:
+            left = deadline - time.monotonic()
+            if left <= 0:
+                raise TimeoutError(f"rank 0 waited {_CONNECT_TIMEOUT_S:.0f} s for "
+                                   f"{size - 1} rank(s) at {address}")
+            server.settimeout(left)
+            try:
+                conn, _addr = server.accept()
+            except socket.timeout:
+                continue
+            # the hello is read under the rendezvous deadline: a connection that says
+            # nothing, or a stranger, is dropped and does not hold up the others
+            try:
+                conn.settimeout(max(1.0, min(30.0, deadline - time.monotonic())))
+                _authenticate(conn, family, serving=True)
+                magic, peer, peer_size = _HELLO.unpack(_recv_exact(conn, _HELLO.size))
+                if magic != _MAGIC or peer_size != size or not 0 < peer < size \
+                        or self._peers[peer] is not None:
+                    raise PermissionError(f"unexpected hello (rank {peer} of {peer_size})")
+            except (OSError, PermissionError, struct.error) as exc:
+                log.warning("rendezvous at %s: dropped a connection (%s)", address, exc)
+                conn.close()
+                continue
+            conn.settimeout(None)
             if family == socket.AF_INET:
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send_msg(conn, pickle.dumps(rank))
-            self._peers[0] = conn
+            self._peers[peer] = conn
+            joined += 1
+
+    def _join(self, family, target) -> None:
+        deadline = time.monotonic() + _CONNECT_TIMEOUT_S
+        while True:
+            conn = socket.socket(family, socket.SOCK_STREAM)
+            try:
+                conn.connect(target)
+                break
+            except (ConnectionRefusedError, FileNotFoundError, OSError):
+                conn.close()
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rank {self.rank} could not reach rank 0 at "
+                                       f"{self.address}") from None
+                time.sleep(0.05)
+        self._peers[0] = conn
+        conn.settimeout(max(1.0, deadline - time.monotonic()))
+        _authenticate(conn, family, serving=False)
+        conn.sendall(_HELLO.pack(_MAGIC, self.rank, self.size))
+        conn.settimeout(None)
+        if family == socket.AF_INET:
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
 
     def gather(self, obj) -> Optional[list]:
         """Every rank's object in rank order on rank 0, None elsewhere."""
@@ -215,8 +304,10 @@ def init(rank: Optional[int] = None, world_size: Optional[int] = None,
 
     Selects GPU ``local_rank % device_count`` for this process (``config.device_index``),
     connects the host channel and, when every rank has a GPU of its own, creates the RCCL
-    communicator.  ``transport`` (or ``MDX_COMM_TRANSPORT``): ``auto`` (default),
-    ``host``, ``rccl``.
+    communicator.  ``transport`` (or ``MDX_COMM_TRANSPORT``): ``auto`` (default: RCCL when
+    every rank owns a GPU, and then a failure to set it up raises; the host channel when
+    ranks share a GPU or have none), ``host`` (the host channel, by request), ``rccl``
+    (RCCL or an error).  Nothing is left half-initialised when this raises.
     """
     if _state.initialised:
         return _state.rank, _state.size
@@ -231,75 +322,112 @@ def init(rank: Optional[int] = None, world_size: Optional[int] = None,
     transport = (transport or os.environ.get("MDX_COMM_TRANSPORT", "auto")).lower()
     if transport not in ("auto", "host", "rccl"):
         raise ValueError("transport must be auto, host or rccl")
-    _state.rank, _state.size, _state.local_rank = rank, world_size, local_rank
-    _state.initialised = True
     if world_size == 1 and transport != "rccl":
+        _state.rank, _state.size, _state.local_rank = rank, world_size, local_rank
         _state.transport = "none"
+        _state.initialised = True
         return rank, world_size
 
+    pending = _State()
+    pending.rank, pending.size, pending.local_rank = rank, world_size, local_rank
+    try:
+        _join_job(pending, transport, address)
+    except BaseException:
+        # a communicator a peer may still be initialising is left alone (destroying it
+        # could pull the ground from under that peer); the sockets are ours to close
+        if pending.channel is not None:
+            pending.channel.close()
+        raise
+    _state.__dict__.update(pending.__dict__)
+    _state.initialised = True
+    atexit.register(shutdown)
+    return rank, world_size
+
+
+def _join_job(state: "_State", transport: str, address: Optional[str]) -> None:
+    """The part of init() that can fail: fills ``state`` (channel, device, communicator)."""
     from . import _lib
     from .utils.config import config
 
+    rank, world_size, local_rank = state.rank, state.size, state.local_rank
     n_devices = _lib.device_count()
     if n_devices > 0:
         if config.device_ids:
-            _state.device_index = int(config.device_ids[local_rank % len(config.device_ids)])
+            state.device_index = int(config.device_ids[local_rank % len(config.device_ids)])
         else:
-            _state.device_index = local_rank % n_devices
-        config.device_index = _state.device_index
-        _lib.check(_lib.load().mdx_set_device(_state.device_index))
-    _state.channel = HostChannel(rank, world_size, address or default_address())
-    _state.transport = "host"
-    atexit.register(shutdown)
+            state.device_index = local_rank % n_devices
+        config.device_index = state.device_index
+        _lib.check(_lib.load().mdx_set_device(state.device_index))
+    state.channel = HostChannel(rank, world_size, address or default_address())
+    state.transport = "host"
 
     # one GPU per rank and librccl present on every rank -> device collectives
     lib = _lib.load()
-    mine = (socket.gethostname(), _state.device_index,
+    mine = (socket.gethostname(), state.device_index,
             bool(n_devices > 0 and lib.mdx_comm_available()))
-    everyone = _state.channel.allgather(mine)
-    distinct = len({(h, d) for h, d, _ in everyone}) == world_size
-    usable = all(ok for _, _, ok in everyone) and distinct
-    if transport == "rccl" and not usable:
-        raise RuntimeError("MDX_COMM_TRANSPORT=rccl, but the ranks do not each own a GPU "
-                           f"with a loadable librccl.so: {everyone}")
-    if transport == "host" or not usable:
-        return rank, world_size
+    everyone = state.channel.allgather(mine)
+    own_gpu = len({(h, d) for h, d, _ in everyone}) == world_size and \
+        all(d is not None for _, d, _ in everyone)
+    loadable = all(ok for _, _, ok in everyone)
+    if transport == "host":
+        return
+    if not own_gpu:
+        if transport == "rccl":
+            raise RuntimeError("MDX_COMM_TRANSPORT=rccl, but the ranks do not each own a "
+                               f"GPU: {everyone}")
+        return  # ranks sharing a GPU (or without one): only the host channel can serve them
+    if not loadable:
+        raise RuntimeError("every rank owns a GPU but librccl.so cannot be loaded on all of "
+                           f"them ({everyone}); set MDX_COMM_TRANSPORT=host to run the sums "
+                           "through the host channel instead")
     uid = ctypes.create_string_buffer(_lib.MDX_COMM_ID_BYTES)
     if rank == 0:
         _lib.check(lib.mdx_comm_unique_id(uid, _lib.MDX_COMM_ID_BYTES))
-    uid_bytes = _state.channel.bcast(uid.raw if rank == 0 else None)
+    uid_bytes = state.channel.bcast(uid.raw if rank == 0 else None)
     # The communicator is created on a helper thread: if a peer never shows up (or the
-    # node's fabric is misconfigured) ncclCommInitRank blocks for good, and a calculator
-    # run should then go on with host sums rather than hang.
+    # node's fabric is misconfigured) ncclCommInitRank blocks for good; the job should
+    # then end with an error on every rank rather than hang.  A thread that is still
+    # inside the call when the time is up is abandoned (it may finish later; the process
+    # is about to fail anyway).
     handle = ctypes.c_void_p()
     outcome = {}
 
     def create():
-        lib.mdx_set_device(_state.device_index)  # the current device is a per-thread setting
+        lib.mdx_set_device(state.device_index)  # the current device is a per-thread setting
         rc_ = lib.mdx_comm_create(ctypes.byref(handle), rank, world_size, uid_bytes,
                                   _lib.MDX_COMM_ID_BYTES)
-        outcome["rc"] = rc_
         outcome["error"] = None if rc_ == 0 else lib.mdx_last_error().decode("utf-8", "replace")
 
     import threading
     worker = threading.Thread(target=create, name="mdx-comm-create", daemon=True)
     worker.start()
     worker.join(float(os.environ.get("MDX_COMM_INIT_TIMEOUT", "120")))
-    timed_out = worker.is_alive()
-    rc = outcome.get("rc", -1)
-    error = "ncclCommInitRank did not return in time" if timed_out else outcome.get("error")
-    errors = _state.channel.allgather(error)
+    if worker.is_alive():
+        error = "ncclCommInitRank did not return in time"
+    else:
+        error = outcome.get("error", "mdx_comm_create did not report")
+    errors = state.channel.allgather(error)
     if any(e is not None for e in errors):
-        if rc == 0 and not timed_out:
-            lib.mdx_comm_destroy(handle)
-        if transport == "rccl":
-            raise RuntimeError(f"RCCL communicator could not be created: {errors}")
-        log.warning("RCCL communicator could not be created (%s); sums go through the "
-                    "host channel", [e for e in errors if e])
-        return rank, world_size
-    _state.comm = handle.value
-    _state.transport = "rccl"
-    return rank, world_size
+        raise RuntimeError(
+            "the RCCL communicator could not be created: "
+            f"{ {r: e for r, e in enumerate(errors) if e} }; the ranks each own a GPU, so "
+            "this is not downgraded to host sums (ask for them with MDX_COMM_TRANSPORT=host)")
+    state.comm = handle.value
+    state.transport = "rccl"
+
+
+def comm_ranks() -> Optional[int]:
+    """Number of ranks the RCCL communicator reports for itself (``mdx_comm_rank``), None
+    when the sums do not go through RCCL."""
+    _ensure()
+    if _state.comm is None:
+        return None
+    from . import _lib
+    r, n = ctypes.c_int(-1), ctypes.c_int(-1)
+    _lib.check(_lib.load().mdx_comm_rank(_state.comm, ctypes.byref(r), ctypes.byref(n)))
+    if r.value != _state.rank:
+        raise RuntimeError(f"RCCL reports rank {r.value}, the job says {_state.rank}")
+    return int(n.value)
 
 
 def shutdown() -> None:
@@ -490,6 +618,7 @@ def launch(argv: Sequence[str], n_ranks: int, env: Optional[dict] = None,
         base.pop(name, None)
     base["MDX_WORLD_SIZE"] = str(int(n_ranks))
     base["MDX_COMM_ADDR"] = f"unix:mdx-launch-{os.getpid()}-{time.monotonic_ns()}"
+    base.setdefault("MDX_COMM_TOKEN", secrets.token_hex(32))
     procs = []
     for r in range(int(n_ranks)):
         child = dict(base, MDX_RANK=str(r), MDX_LOCAL_RANK=str(r))

@@ -12,16 +12,24 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 
-def run_ranks(target, world, *args, timeout=240, transport=None):
-    """Start ``world`` processes running ``target(rank, world, address, queue, *args)``;
-    returns their queue items ordered by rank.  A rank that raises reports the traceback."""
+def run_ranks(target, world, *args, timeout=240, transport=None, address=None, raw=False):
+    """Start ``world`` processes that join the job and run ``target(rank, world, *args)``;
+    returns their queue items ordered by rank.  A rank that raises reports the traceback.
+    ``raw``: the process runs ``target(rank, world, address, queue, *args)`` and joins (or
+    fails to join) the job itself."""
     import multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
-    address = f"unix:mdx-test-{os.getpid()}-{np.random.default_rng().integers(1 << 62)}"
-    procs = [ctx.Process(target=_guarded, args=(target, r, world, address, queue, args, transport))
-             for r in range(world)]
+    if address is None:
+        address = f"unix:mdx-test-{os.getpid()}-{np.random.default_rng().integers(1 << 62)}"
+    if raw:
+        procs = [ctx.Process(target=target, args=(r, world, address, queue, *args))
+                 for r in range(world)]
+    else:
+        procs = [ctx.Process(target=_guarded,
+                             args=(target, r, world, address, queue, args, transport))
+                 for r in range(world)]
     for p in procs:
         p.start()
     results = []
@@ -266,3 +274,82 @@ def rccl_single_rank(rank, world):
     out["rdf_ok"] = bool(np.array_equal(rdf.read(), before) and before.sum() > 0)
     rdf.close()
     return out
+
+
+def stub_gpu_per_rank(rank, world, create_fails_on=()):
+    """Makes this process look like one of ``world`` ranks that each own a GPU with a
+    loadable librccl, without touching a device: the rendezvous then takes the RCCL branch.
+    ``mdx_comm_create`` fails on the listed ranks."""
+    from lammps_analysis_amd import _lib
+
+    real = _lib.load()
+
+    class Stub:
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def mdx_set_device(self, device):
+            return 0
+
+        def mdx_comm_available(self):
+            return 1
+
+        def mdx_comm_unique_id(self, buf, n):
+            return 0
+
+        def mdx_comm_create(self, handle, r, n, uid, n_bytes):
+            return -2 if r in create_fails_on else 0
+
+        def mdx_comm_destroy(self, handle):
+            return 0
+
+        def mdx_last_error(self):
+            return b"stub: ncclCommInitRank failed"
+
+    stub = Stub()
+    _lib.load = lambda: stub
+    _lib.device_count = lambda: world
+
+
+def rccl_setup_fails(rank, world, address, queue, transport):
+    """Joins a job whose communicator cannot be created on rank 1 and reports what
+    ``parallel.init`` did about it."""
+    try:
+        from lammps_analysis_amd import parallel
+        stub_gpu_per_rank(rank, world, create_fails_on=(1,))
+        try:
+            parallel.init(rank=rank, world_size=world, local_rank=rank, address=address,
+                          transport=transport)
+            outcome = "joined:" + parallel.transport()
+            parallel.barrier()
+            parallel.shutdown()
+        except RuntimeError as exc:
+            outcome = f"error:{exc}|initialised={parallel._state.initialised}" \
+                      f"|channel={parallel._state.channel}"
+        queue.put((rank, outcome))
+    except BaseException:
+        queue.put((rank, traceback.format_exc()))
+
+
+def token_exchange(rank, world, address, queue, token):
+    """A tcp: rendezvous with this rank's idea of the shared secret."""
+    try:
+        from lammps_analysis_amd import parallel
+        if token is None:
+            os.environ.pop("MDX_COMM_TOKEN", None)
+        else:
+            os.environ["MDX_COMM_TOKEN"] = token
+        os.environ["MDX_COMM_TIMEOUT"] = "6"
+        import importlib
+        importlib.reload(parallel)
+        try:
+            parallel.init(rank=rank, world_size=world, local_rank=rank, address=address)
+            total = parallel.all_reduce_sum(np.array([rank + 1.0]))
+            outcome = f"sum={total[0]:.0f}"
+            parallel.barrier()
+            parallel.shutdown()
+        except (PermissionError, TimeoutError, ConnectionError) as exc:
+            outcome = f"{type(exc).__name__}|initialised={parallel._state.initialised}"
+        queue.put((rank, outcome))
+    except BaseException:
+        queue.put((rank, traceback.format_exc()))

@@ -98,6 +98,40 @@ def test_momentum_and_thermal_flux(gpu):
                                orc.thermal_flux(stress, vel, ke, pe), rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("n,t,dtype", [
+    (1, 2, np.float32), (7, 126, np.float32), (65, 128, np.float32), (33, 130, np.float32),
+    (300, 1000, np.float32), (70, 4098, np.float32), (513, 640, np.float32),
+    (40, 511, np.float32),    # odd frame count: the rows lose their alignment, generic kernels
+    (40, 256, np.float64),    # float64 input: generic kernels
+])
+def test_flux_reductions_around_tile_edges(gpu, n, t, dtype):
+    """MomentumFlux / ThermalFlux / IntegratedHeatCurrent sums
+    (mdsuite/transformations/momentum_flux.py:45-55, thermal_flux.py:51-92,
+    integrated_heat_current.py:48-60) against the oracle, at frame counts around the
+    128-frame slices of the streaming kernels and atom counts around the chunking."""
+    rng = np.random.default_rng(n * 10007 + t)
+    stress = rng.normal(size=(n, t, 6)).astype(dtype)
+    vel = rng.normal(size=(n, t, 3)).astype(dtype)
+    ke = rng.random((n, t, 1)).astype(dtype)
+    pe = rng.normal(size=(n, t, 1)).astype(dtype)
+    tol = dict(rtol=0, atol=1e-12 * n)
+    np.testing.assert_allclose(gpu.momentum_flux(stress), orc.momentum_flux([stress]), **tol)
+    np.testing.assert_allclose(gpu.thermal_flux(stress, vel, ke, pe),
+                               orc.thermal_flux(stress, vel, ke, pe), **tol)
+    np.testing.assert_allclose(gpu.energy_weighted_sum(vel, ke, pe),
+                               orc.integrated_heat_current([vel], [ke], [pe]), **tol)
+    # accumulate over a second species, device-resident input
+    dev = [gpu.DeviceArray.from_numpy(a) for a in (stress, vel, ke, pe)]
+    out = gpu.thermal_flux(stress, vel, ke, pe)
+    out = gpu.thermal_flux(*dev, out=out, accumulate=True)
+    np.testing.assert_allclose(out, 2 * orc.thermal_flux(stress, vel, ke, pe),
+                               rtol=0, atol=2e-12 * n)
+    out = gpu.momentum_flux(dev[0], out=gpu.momentum_flux(stress), accumulate=True)
+    np.testing.assert_allclose(out, 2 * orc.momentum_flux([stress]), rtol=0, atol=2e-12 * n)
+    for d in dev:
+        d.free()
+
+
 # ------------------------------------------------------------------------- ACF
 
 def _per_window_reference(x, ct, w0, w1, tau):

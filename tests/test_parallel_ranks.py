@@ -83,3 +83,75 @@ def test_single_process_needs_no_transport():
     x = np.arange(5.0)
     assert parallel.all_reduce_sum(x) is x
     assert parallel.run_on_writer(lambda: 7) == 7
+
+
+@pytest.mark.parametrize("transport", ("auto", "rccl"))
+def test_failed_rccl_setup_is_an_error_on_every_rank(transport):
+    """Every rank owns a GPU (stubbed) and the communicator cannot be created on one of
+    them: no rank may carry on with host sums, and none is left half-initialised."""
+    results = rw.run_ranks(rw.rccl_setup_fails, 2, transport, raw=True)
+    for rank, outcome in results:
+        assert outcome.startswith("error:the RCCL communicator could not be created"), outcome
+        assert "stub: ncclCommInitRank failed" in outcome
+        assert outcome.endswith("|initialised=False|channel=None")
+
+
+def test_host_transport_by_name_skips_rccl():
+    results = rw.run_ranks(rw.rccl_setup_fails, 2, "host", raw=True)
+    assert [o for _, o in results] == ["joined:host", "joined:host"]
+
+
+def test_launcher_reports_the_failed_setup_as_exit_status(tmp_path):
+    """The same failure through ``parallel.launch`` (what ``bench.py --gpus N`` uses): the
+    launcher's status is non-zero."""
+    script = tmp_path / "job.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {str(rw.ROOT)!r}); sys.path.insert(0, {str(rw.ROOT / 'tests')!r})\n"
+        "import _rank_workers as rw\n"
+        "from lammps_analysis_amd import parallel\n"
+        "rank, world = int(os.environ['MDX_RANK']), int(os.environ['MDX_WORLD_SIZE'])\n"
+        "rw.stub_gpu_per_rank(rank, world, create_fails_on=(0,))\n"
+        "parallel.init()\n"
+        "print('joined', parallel.transport())\n")
+    assert parallel.launch([str(script)], 2, timeout=120) != 0
+    env = dict(__import__("os").environ, MDX_COMM_TRANSPORT="host")
+    assert parallel.launch([str(script)], 2, env=env, timeout=120) == 0
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_tcp_rendezvous_needs_the_shared_token():
+    address = f"tcp:127.0.0.1:{_free_port()}"
+    results = rw.run_ranks(rw.token_exchange, 2, "s3cret", address=address, raw=True)
+    assert [o for _, o in results] == ["sum=3", "sum=3"]
+    # no token at all: refused before anything is read from the wire
+    address = f"tcp:127.0.0.1:{_free_port()}"
+    results = rw.run_ranks(rw.token_exchange, 2, None, address=address, raw=True)
+    for _, outcome in results:
+        assert outcome.endswith("|initialised=False")
+        assert outcome.split("|")[0] in ("PermissionError", "TimeoutError", "ConnectionError")
+
+
+def test_tcp_rendezvous_drops_a_peer_with_the_wrong_token():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    address = f"tcp:127.0.0.1:{_free_port()}"
+    procs = [ctx.Process(target=rw.token_exchange, args=(0, 2, address, queue, "right")),
+             ctx.Process(target=rw.token_exchange, args=(1, 2, address, queue, "wrong"))]
+    for p in procs:
+        p.start()
+    outcomes = dict(queue.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    # rank 1 is refused (or sees the server hang up); rank 0 never unpickles anything from
+    # it and gives up when the rendezvous time is over
+    assert outcomes[1].split("|")[0] in ("PermissionError", "ConnectionError")
+    assert outcomes[0].split("|")[0] == "TimeoutError"
+    assert all(o.endswith("|initialised=False") for o in outcomes.values())

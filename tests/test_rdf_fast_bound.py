@@ -1,0 +1,110 @@
+"""The error bound behind the default RDF kernel, checked on the host.
+
+``rdf_fast_kernel`` counts a pair in the bin of an approximate position unless that
+position lies within ``edge_units`` grid steps above a bin edge; the library derives
+``edge_units`` from a bound on the distance between the approximate and the literal
+position (mdx_rdf.hip ``rdf_fast_setup``).  Here the kernel's arithmetic, restated in NumPy
+float32 with the hardware square root allowed to be one step off either way
+(oracle/rdf_fast_model.py), runs on pairs built to sit on the worst places -- coordinate
+differences at 0, L/2 and L, distances within a few float32 steps of bin edges and of
+the cutoff, long thin boxes, bin counts up to the kernel's limit -- with the constants the
+library itself reports through ``mdx_rdf_fast_plan`` (a host-only call: no GPU needed).
+The literal side follows radial_distribution_function.py:647-689, linalg.py:84-99 and the
+``tf.histogram_fixed_width`` CPU rule.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from lammps_analysis_amd import _lib
+from oracle import rdf_fast_model as model
+
+
+def library_plan(box, cutoff, nbins):
+    lib = _lib.load()
+    plan = _lib.RdfFastPlan()
+    cbox = (ctypes.c_float * 3)(*[float(b) for b in box])
+    _lib.check(lib.mdx_rdf_fast_plan(cbox, ctypes.c_float(float(np.float32(cutoff))), int(nbins),
+                                     ctypes.byref(plan)))
+    return model.plan_dict(plan)
+
+
+def edges_of_interest(nbins, rng, extra=400):
+    fixed = [1, 2, 3, nbins // 2, nbins - 2, nbins - 1, nbins]
+    drawn = rng.integers(1, nbins + 1, extra)
+    return np.unique(np.concatenate([np.array(fixed), drawn]).clip(1, nbins))
+
+
+GEOMETRIES = [
+    # box, cutoff, nbins
+    ((65.0, 65.0, 65.0), 32.4, 3240),            # the benchmark geometry
+    ((100.0, 100.0, 100.0), 49.9, 4990),         # 100k-atom water box
+    ((10.0, 40.0, 160.0), 4.9, 490),             # aspect 1:4:16, cutoff from the short edge
+    ((10.0, 40.0, 160.0), 60.0, 3000),           # the same box, cutoff beyond two half edges
+    ((34.8, 34.8, 34.8), 17.3, 1730),
+    ((7.3, 9.1, 8.2), 3.55, 355),
+    ((65.0, 65.0, 65.0), 56.0, 2000),            # cutoff near the half diagonal
+]
+# bin counts at 2^k - 3 (the mantissa split changes at nbins + 3 = 2^k) for k = 6..15
+GEOMETRIES += [((65.0, 65.0, 65.0), 32.4, (1 << k) - 3) for k in range(6, 16)]
+GEOMETRIES += [((10.0, 40.0, 160.0), 4.9, (1 << k) - 3) for k in (8, 12, 15)]
+GEOMETRIES += [((65.0, 65.0, 65.0), 32.4, (1 << k) - 2) for k in (7, 11, 14)]
+
+
+@pytest.mark.parametrize("box,cutoff,nbins", GEOMETRIES)
+def test_fast_kernel_decisions_equal_the_literal_rule(box, cutoff, nbins):
+    plan = library_plan(box, cutoff, nbins)
+    if not plan["usable"]:
+        pytest.skip("the library does not use the fast kernel for this geometry")
+    rng = np.random.default_rng(nbins * 7919 + int(box[0] * 10))
+    cutoff32 = np.float32(cutoff)
+    total = {"pairs": 0, "resolved": 0}
+    sets = [
+        model.pairs_near_fold_points(box, 100_000, rng),
+        model.pairs_near_bin_edges(box, cutoff32, nbins, edges_of_interest(nbins, rng), 160, rng),
+        model.pairs_near_bin_edges(box, cutoff32, nbins, [nbins], 20_000, rng),
+        model.pairs_near_bin_edges(box, cutoff32, nbins, [nbins - 1, 1], 10_000, rng,
+                                   through_wrap=False),
+        model.uniform_pairs(box, 200_000, rng),
+    ]
+    worst_high = 0.0
+    for xi, xj in sets:
+        report = model.check_pairs(xi, xj, box, cutoff32, nbins, plan)
+        total["pairs"] += report["pairs"]
+        total["resolved"] += report["resolved"]
+        worst_high = max(worst_high, report["worst_high"])
+    # the edge sets must really have landed inside the band the kernel re-evaluates
+    assert total["resolved"] > 1000
+    grid = 1.0 / (1 << plan["frac_bits"])
+    assert worst_high <= plan["edge_units"] * grid
+
+
+def test_plan_reports_unusable_geometries():
+    # more bins than the mantissa split admits: the table kernel takes over
+    plan = library_plan((65.0, 65.0, 65.0), 32.4, 40000)
+    assert plan["usable"] == 0
+    plan = library_plan((65.0, 65.0, 65.0), 32.4, 3240)
+    assert plan["usable"] == 1 and plan["frac_bits"] == 11
+    assert np.float32(plan["magic"]) == np.float32(4096.0 + plan["edge_units"] / 2 / 2048.0)
+
+
+def test_fma_model_rounds_once():
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=200_000).astype(np.float32)
+    b = rng.normal(size=200_000).astype(np.float32)
+    c = (-(a.astype(np.float64) * b.astype(np.float64))).astype(np.float32)
+    c = model._nudge(c, rng.integers(-2, 3, a.size))
+    got = model.fma32(a, b, c).astype(np.float64)
+    # exact reference through integers: scale everything to a common binary exponent
+    from fractions import Fraction
+    idx = rng.integers(0, a.size, 300)
+    for i in idx:
+        exact = Fraction(float(a[i])) * Fraction(float(b[i])) + Fraction(float(c[i]))
+        lo = np.float32(float(exact))
+        # float(Fraction) rounds once to float64; decide the float32 neighbours exactly
+        cands = {float(lo), float(np.nextafter(lo, np.float32(np.inf))),
+                 float(np.nextafter(lo, np.float32(-np.inf)))}
+        best = min(cands, key=lambda v: (abs(Fraction(v) - exact),
+                                         int(np.float32(v).view(np.uint32)) & 1))
+        assert got[i] == best
