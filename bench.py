@@ -13,12 +13,17 @@ per second over all ranks.  With N > 1 every rank owns its own frames (weak
 scaling, no collective inside a step); the per-rank histograms are summed once at
 the end with one all-reduce, outside the timed steps (reported separately).
 
-Also measured in the same run, outside the timed steps and reported as extra
-keys: the Green-Kubo chain of configs[2] (atom reduction of a 10 000-atom velocity
-block to the ionic current, then the windowed autocorrelation, data_range 500) and
-the CPU baseline (C restatement of the reference algorithm, OpenMP) on a bounded
-sample of the same trajectory, whose histogram is also compared bit for bit with
-the GPU result for those frames.
+Also measured in the same run (one rank only), outside the timed steps and reported as
+extra keys: the Green-Kubo chain of configs[2] (atom reduction of a 10 000-atom velocity
+block to the ionic current, then the windowed autocorrelation, data_range 500) with its
+own CPU baseline; the flux reductions that feed configs[4]; the CPU baselines of the RDF
+(C restatement of the reference algorithm with OpenMP, and the literal NumPy restatement)
+on bounded samples of the same trajectory, whose histograms are also compared bit for bit
+with the GPU's; and the same two calculators end to end through the product API on a
+trajectory written to the on-disk store (``--api-frames``).
+
+With N > 1 the sums of the exchange step must go through RCCL: a run whose ranks fell
+back to the host channel exits non-zero unless MDX_COMM_TRANSPORT=host asked for that.
 """
 from __future__ import annotations
 
@@ -84,27 +89,58 @@ def parse_args():
                     help="leave out the host-memory side measurement")
     ap.add_argument("--kernel", choices=("fast", "table", "literal"), default="fast",
                     help="RDF pair kernel to time (all three give identical counts)")
+    ap.add_argument("--literal-frames", type=int, default=1,
+                    help="frames of the literal NumPy baseline (0 disables it)")
+    ap.add_argument("--flux-atoms", type=int, default=5000,
+                    help="atoms of the flux-reduction side measurement over 100 000 frames "
+                         "(0 disables it)")
+    ap.add_argument("--api-frames", type=int, default=20000,
+                    help="frames of the trajectory written to the on-disk store for the "
+                         "end-to-end measurement through the calculators (0 disables it)")
+    ap.add_argument("--cutoff", type=float, default=0.0,
+                    help="RDF cutoff of the timed steps; 0 = the reference's default L/2 - "
+                         "0.1 (the headline).  Any other value is a side experiment.")
     return ap.parse_args()
 
 
-def recorded(kernel_key: str):
-    """Per-launch counter means of a kernel from the committed PMC summary of this command
-    with default flags (profiles/r02_pmc.json; counters cannot be read from inside the
-    process); {} when not recorded."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc.json")
+PMC_SUMMARY = "profiles/r03_pmc.json"
+
+
+def recorded(kernel_key: str, units_per_launch: float = None, unit: str = None):
+    """Per-launch counter means of a kernel from the committed PMC summary (counters
+    cannot be read from inside the process), scaled to this run's launch shape.
+
+    The summary's ``__meta__`` says how many units (frames) one recorded launch of the
+    kernel processed; counters are proportional to them, so a launch of another size gets
+    the recorded values times the ratio.  {} when the kernel, or the size of its recorded
+    launch, is not on record."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SUMMARY)
     try:
         with open(path) as fh:
             table = json.load(fh)
     except (OSError, ValueError):
         return {}
+    meta = table.get("__meta__", {})
     entries = [v for k, v in table.items() if k.startswith(kernel_key)]
     if not entries:
         return {}
     # several grids of one kernel: the full-size launches are the longest ones
-    return max(entries, key=lambda v: v.get("mean_duration_us_under_pmc", 0.0))
+    entry = dict(max(entries, key=lambda v: v.get("mean_duration_us_under_pmc", 0.0)))
+    if unit is None:
+        return entry
+    on_record = meta.get(unit)
+    if not on_record or not units_per_launch:
+        return {}
+    ratio = float(units_per_launch) / float(on_record)
+    scaled = {k: (v * ratio if isinstance(v, (int, float)) and k != "launches_seen" else v)
+              for k, v in entry.items()}
+    scaled["scaled_from_units_per_launch"] = on_record
+    return scaled
 
 
 def traffic_of(entry: dict):
+    """HBM bytes of one launch: FETCH_SIZE doubled (gfx950 tallies a 128-byte read as
+    64) plus WRITE_SIZE."""
     if "fetch_bytes_x2" in entry and "write_bytes" in entry:
         return entry["fetch_bytes_x2"] + entry["write_bytes"]
     return None
@@ -136,6 +172,14 @@ def main() -> None:
     rank, world = parallel.init(transport="rccl" if (force and env_world is None) else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    # parallel.init raises when ranks that each own a GPU cannot set up RCCL; ranks that
+    # share a GPU land on the host channel by design, which this benchmark accepts only
+    # when it was asked for by name
+    host_asked = os.environ.get("MDX_COMM_TRANSPORT", "").lower() == "host"
+    if world > 1 and parallel.transport() != "rccl" and not host_asked:
+        raise SystemExit(f"--gpus {world}: the exchange step would run over the "
+                         f"'{parallel.transport()}' transport, not RCCL (ranks sharing a "
+                         "GPU?); set MDX_COMM_TRANSPORT=host to measure that on purpose")
     local_rank = int(os.environ.get("MDX_LOCAL_RANK") or os.environ.get("LOCAL_RANK") or rank)
     engine.set_device(local_rank % _lib.device_count())
 
@@ -146,7 +190,7 @@ def main() -> None:
     work = WORKLOADS[args.workload]
     n_per_species = list(work["species"])
     box = work["box"]
-    cutoff = np.float32(box / 2 - 0.1)
+    cutoff = np.float32(args.cutoff if args.cutoff > 0 else box / 2 - 0.1)
     nbins = int(cutoff / 0.01)
     shard_tiles = args.workload == "water"
     steps, warmup = args.steps, args.warmup
@@ -219,8 +263,11 @@ def main() -> None:
     frames_per_launch = steps * fps / launches
     kernel_name = {"fast": "rdf_fast_kernel", "table": "rdf_tile_kernel<false>",
                    "literal": "rdf_tile_kernel<true>"}[args.kernel]
-    default_run = args.workload == "nacl" and args.kernel == "fast" and args.frames_per_step == 0
-    pmc = recorded(kernel_name) if default_run else {}
+    # counters on record belong to the headline geometry; they scale with the frames of a
+    # launch, whatever --steps / --frames-per-step make of it
+    on_record = args.workload == "nacl" and args.kernel == "fast" and args.cutoff <= 0 \
+        and world == 1
+    pmc = recorded(kernel_name, frames_per_launch, "rdf_frames_per_launch") if on_record else {}
     achieved_gbps = (bytes_per_frame * frames_per_launch) / (tile_avg_ms * 1e-3) / 1e9
     roofline = {
         "kernel": kernel_name,
@@ -230,9 +277,13 @@ def main() -> None:
         "unit": "GB/s",
         "frac": achieved_gbps / HBM_PEAK_GBPS,
         "traffic": traffic_of(pmc),
-        "traffic_source": "profiles/r02_pmc.json: separate rocprofv3 --pmc FETCH_SIZE and "
+        "traffic_source": f"{PMC_SUMMARY}: separate rocprofv3 --pmc FETCH_SIZE and "
                           "WRITE_SIZE passes over this command; bytes per launch = "
-                          "2*FETCH_SIZE (gfx950 counts 128-B reads as 64 B) + WRITE_SIZE",
+                          "2*FETCH_SIZE (gfx950 counts 128-B reads as 64 B) + WRITE_SIZE, "
+                          "scaled by frames per launch "
+                          f"({pmc.get('scaled_from_units_per_launch')} on record)",
+        "traffic_over_algorithmic": (traffic_of(pmc) / (bytes_per_frame * frames_per_launch))
+        if traffic_of(pmc) else None,
         "avg_launch_ms": tile_avg_ms,
         "launches": tile_launches,
         "algorithmic_bytes_per_launch": bytes_per_frame * frames_per_launch,
@@ -298,25 +349,41 @@ def main() -> None:
         "roofline": roofline,
         "valu": valu,
         "pairs_counted": int(hist_total.sum()),
+        # the exchange step: which transport carried it, how many ranks the RCCL
+        # communicator itself reports, and what the one histogram all-reduce took
+        "transport": parallel.transport(),
+        "rccl_ranks": parallel.comm_ranks(),
         "allreduce_ms": allreduce_ms,
         "gk_acf_frames_per_s": None,
     }
+    if world > 1 and result["transport"] == "rccl" and result["rccl_ranks"] != world:
+        raise SystemExit(f"RCCL communicator spans {result['rccl_ranks']} rank(s), the job "
+                         f"has {world}")
 
-    if rank == 0:
-        if args.cpu_frames > 0 and not shard_tiles:
-            result["cpu_baseline"] = cpu_baseline(engine, species, n_frames, args.cpu_frames,
-                                                  rank)
+    # side measurements: one-rank runs only (with N > 1 the other ranks would sit idle,
+    # and the CPU baselines belong to the N = 1 line)
+    side = rank == 0 and world == 1 and not shard_tiles and args.cutoff <= 0
+    if side and args.cpu_frames > 0:
+        result["cpu_baseline"] = cpu_baseline(engine, species, n_frames, args.cpu_frames, rank)
+    if side and args.literal_frames > 0:
+        result["cpu_baseline_literal"] = cpu_baseline_literal(engine, species, n_frames,
+                                                              args.literal_frames, rank)
     rdf.close()
     for arr in species:
         arr.free()
-    if rank == 0:
-        if args.gk_frames > 0 and not shard_tiles:
-            result["gk_acf"] = gk_side_measurement(engine, args.gk_frames)
+    if side:
+        if args.gk_frames > 0:
+            result["gk_acf"] = gk_side_measurement(engine, args.gk_frames,
+                                                   with_cpu=args.cpu_frames > 0)
             # the second half of the metric: frames/s of the GreenKuboIonicConductivity
             # chain (configs[2]) on this GPU, measured outside the timed steps
             result["gk_acf_frames_per_s"] = result["gk_acf"]["frames_per_s"]
-        if not args.skip_host_input and not shard_tiles:
+        if args.flux_atoms > 0:
+            result["flux_reductions"] = flux_side_measurement(engine, args.flux_atoms, 100000)
+        if not args.skip_host_input:
             result["host_input"] = host_input_measurement(engine, min(fps, 1024))
+        if args.api_frames > 0:
+            result["api_end_to_end"] = api_measurement(args.api_frames)
     parallel.barrier()
     transport = parallel.transport()
     parallel.shutdown()
@@ -384,7 +451,215 @@ def cpu_baseline(engine, species, n_frames: int, sample: int, rank: int) -> dict
     }
 
 
-def gk_side_measurement(engine, n_frames: int) -> dict:
+def cpu_baseline_literal(engine, species, n_frames: int, sample: int, rank: int) -> dict:
+    """The NumPy restatement that follows the reference line by line (index lists of the
+    upper triangle, gathers, minimum image, boolean masks, the fixed-width histogram rule;
+    oracle/rdf.py) on the first frame(s) of the same trajectory: the closest thing to the
+    reference's own CPU path that can run here, one host thread plus NumPy's."""
+    from oracle import rdf as literal
+
+    sample = min(sample, n_frames)
+    host = []
+    for s_idx, n in enumerate((N_NA, N_CL)):
+        seed = 1000 + s_idx + 2 * rank
+        idx = (np.arange(n, dtype=np.uint64)[:, None] * np.uint64(n_frames * 3)
+               + np.arange(sample * 3, dtype=np.uint64)[None, :])
+        host.append(engine.uniform_fill_at(idx, seed, 0.0, BOX).reshape(n, sample, 3))
+    t0 = time.perf_counter()
+    ref = literal.rdf_histograms(host, ["Na", "Cl"], [BOX] * 3, CUTOFF, NBINS, rdf_minibatch=500)
+    dt = time.perf_counter() - t0
+    check = engine.RdfEngine([N_NA, N_CL], [BOX] * 3, CUTOFF, NBINS)
+    check.accumulate(species, frames=np.arange(sample, dtype=np.int64))
+    got = check.read()
+    check.close()
+    same = all(np.array_equal(got[k], ref[name].astype(np.uint64))
+               for k, name in enumerate(literal.key_names(["Na", "Cl"])))
+    return {
+        "value": sample / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample} frame(s) of the same 10k-atom trajectory, {dt:.2f} s wall, "
+                  "oracle/rdf.py (NumPy, rows of 500 atoms per tile)",
+        "gpu_matches_bit_exact": bool(same),
+    }
+
+
+def gk_cpu_baseline(engine, series_f32: np.ndarray, acf_gpu: np.ndarray, data_range: int,
+                    decay: float, kick: float) -> dict:
+    """CPU side of the Green-Kubo chain (C restatement, OpenMP): the atom reduction on a
+    2 000-frame block of 10 000 atoms, and the windowed autocorrelation of the full ionic
+    current series the GPU chain produced.  Both stages are also compared with the GPU."""
+    from oracle import c_oracle
+
+    threads = c_oracle.num_threads()
+    sample_frames = 2000
+    block = []
+    for seed, n in ((3, N_NA), (4, N_CL)):
+        dev = engine.DeviceArray((n, sample_frames, 3), np.float32)
+        dev.fill_langevin(seed=seed, decay=decay, kick=kick)
+        block.append((dev, dev.to_numpy()))
+    t0 = time.perf_counter()
+    cur = c_oracle.weighted_atom_sum(block[0][1], 1.0) - c_oracle.weighted_atom_sum(block[1][1], 1.0)
+    dt_sum = time.perf_counter() - t0
+    got = engine.weighted_atom_sum(block[0][0], scalar_weight=1.0)
+    got = engine.weighted_atom_sum(block[1][0], scalar_weight=-1.0, out=got, accumulate=True)
+    for dev, _ in block:
+        dev.free()
+    sum_err = float(np.max(np.abs(got - cur)) / np.max(np.abs(cur)))
+
+    n_frames = series_f32.shape[1]
+    n_win = n_frames - data_range
+    t0 = time.perf_counter()
+    acf = c_oracle.acf_windows(series_f32.astype(np.float64), 1, 0, n_win,
+                               np.arange(data_range, dtype=np.int32))
+    dt_acf = time.perf_counter() - t0
+    acf_err = float(np.max(np.abs(acf_gpu - acf)) / np.max(np.abs(acf)))
+    reduce_rate = sample_frames / dt_sum
+    acf_rate = n_frames / dt_acf
+    return {
+        # frames/s of the chain when both stages run at their measured rates
+        "value": 1.0 / (1.0 / reduce_rate + 1.0 / acf_rate),
+        "unit": "frames/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"atom reduction: {sample_frames} frames x 10k atoms, {dt_sum:.3f} s wall; "
+                  f"windowed autocorrelation: all {n_win} windows of the {n_frames}-frame "
+                  f"series, {dt_acf:.2f} s wall; oracle/mdx_oracle.c with OpenMP; value "
+                  "composes the two measured stage rates",
+        "reduce_frames_per_s": reduce_rate,
+        "acf_frames_per_s": acf_rate,
+        "gpu_reduce_max_rel_diff": sum_err,
+        "gpu_acf_max_rel_diff": acf_err,
+        "gpu_matches_1e-6": bool(sum_err <= 1e-6 and acf_err <= 1e-6),
+    }
+
+
+def flux_side_measurement(engine, n_atoms: int, n_frames: int) -> dict:
+    """The reductions that turn per-atom stress / velocity / energy arrays into the series
+    GreenKuboViscosity and GreenKuboThermalConductivity correlate (configs[4] stage A):
+    HBM-bound streams, timed with device-resident input."""
+    stress = engine.DeviceArray((n_atoms, n_frames, 6), np.float32)
+    vel = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    ke = engine.DeviceArray((n_atoms, n_frames, 1), np.float32)
+    pe = engine.DeviceArray((n_atoms, n_frames, 1), np.float32)
+    for seed, arr in enumerate((stress, vel, ke, pe)):
+        arr.fill_uniform(seed=700 + seed, lo=-1.0, hi=1.0)
+    cell = n_atoms * n_frames * 4
+    cases = {
+        "momentum_flux": (lambda: engine.momentum_flux(stress), 6 * cell,
+                          "weighted_sum_kernel<float, 4, true>",
+                          "whole [t][6] rows: the kept components 3..5 share their sectors "
+                          "with the other three (needed bytes are half of this)"),
+        "thermal_flux": (lambda: engine.thermal_flux(stress, vel, ke, pe), 11 * cell,
+                         "flux_stream_kernel<true>", "stress 6 + velocity 3 + two energies"),
+        "energy_weighted_sum": (lambda: engine.energy_weighted_sum(vel, ke, pe), 5 * cell,
+                                "flux_stream_kernel<false>", "vector 3 + two energies"),
+    }
+    out = {"workload": f"{n_atoms} atoms x {n_frames} frames, float32, device resident"}
+    reps = 3
+    for name, (fn, nbytes, kernel, what) in cases.items():
+        fn()  # warm-up
+        engine.profile_enable(True)
+        engine.profile_reset()
+        for _ in range(reps):
+            fn()
+        engine.synchronize()
+        engine.profile_enable(False)
+        ms, launches = engine.profile_query("flux")
+        avg = ms / max(launches, 1)
+        achieved = nbytes / (avg * 1e-3) / 1e9
+        pmc = recorded(kernel) if (n_atoms, n_frames) == (5000, 100000) else {}
+        out[name] = {"kernel": kernel, "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": traffic_of(pmc), "avg_launch_ms": avg, "launches": launches,
+                     "algorithmic_bytes_per_launch": nbytes, "algorithmic_bytes": what}
+    for arr in (stress, vel, ke, pe):
+        arr.free()
+    return out
+
+
+def api_measurement(n_frames: int) -> dict:
+    """The same two calculators as a user runs them: a 10k-atom trajectory written to the
+    on-disk store, then ``project.run.RadialDistributionFunction(number_of_configurations
+    =-1)`` and ``project.run.GreenKuboIonicConductivity()`` (store reads, batching, PCIe,
+    kernels, result files)."""
+    import shutil
+    import tempfile
+
+    import lammps_analysis_amd as mds
+    from lammps_analysis_amd.database.mdsuite_properties import mdsuite_properties
+    from lammps_analysis_amd.database.simulation_database import (SpeciesInfo,
+                                                                  TrajectoryChunkData,
+                                                                  TrajectoryMetadata)
+    from lammps_analysis_amd.file_io.file_read import FileProcessor
+
+    props = [mdsuite_properties.positions, mdsuite_properties.velocities]
+    species = [SpeciesInfo(name=name, n_particles=n, properties=props, charge=q)
+               for name, n, q in (("Na", N_NA, 1.0), ("Cl", N_CL, -1.0))]
+    meta = TrajectoryMetadata(species_list=species, n_configurations=n_frames, sample_rate=1,
+                              box_l=[BOX] * 3)
+    rng = np.random.default_rng(7)
+    chunk_frames = 500
+
+    class Synthetic(FileProcessor):
+        def __str__(self):
+            return "synthetic"
+
+        def _get_metadata(self):
+            return meta
+
+        def get_configurations_generator(self):
+            for f0 in range(0, n_frames, chunk_frames):
+                nf = min(chunk_frames, n_frames - f0)
+                chunk = TrajectoryChunkData(species_list=species, chunk_size=nf)
+                for sp in species:
+                    chunk.add_data(rng.random((nf, sp.n_particles, 3), dtype=np.float32)
+                                   * np.float32(BOX), 0, sp.name, "Positions")
+                    chunk.add_data(rng.standard_normal((nf, sp.n_particles, 3),
+                                                       dtype=np.float32), 0, sp.name,
+                                   "Velocities")
+                yield chunk
+
+    workdir = tempfile.mkdtemp(prefix="mdx_bench_", dir=os.environ.get("TMPDIR") or None)
+    try:
+        project = mds.Project(name="bench", storage_path=workdir)
+        t0 = time.perf_counter()
+        project.add_experiment("melt", timestep=0.002, temperature=1400.0, units="metal",
+                               simulation_data=Synthetic())
+        ingest_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        rdf = project.run.RadialDistributionFunction(number_of_configurations=-1, plot=False)
+        rdf_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        project.run.GreenKuboIonicConductivity(data_range=500, plot=False)
+        gk_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        project.run.GreenKuboIonicConductivity(data_range=500, correlation_time=2, plot=False)
+        gk_again_s = time.perf_counter() - t0
+        keys = sorted(rdf["melt"].data_dict)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    rdf_frames = n_frames - 1   # number_of_configurations=-1 samples n - 1 frames
+    return {
+        "workload": f"10k-atom NaCl trajectory of {n_frames} frames in the on-disk store "
+                    f"({2 * n_frames * 120000 / 1e9:.1f} GB of float32 positions and "
+                    "velocities under $TMPDIR, page cache warm: just written)",
+        "ingest_s": ingest_s,
+        "rdf_frames_per_s": rdf_frames / rdf_s,
+        "rdf_s": rdf_s,
+        "rdf_keys": keys,
+        "gk_ionic_frames_per_s": n_frames / gk_s,
+        "gk_ionic_s": gk_s,
+        "gk_ionic_series_stored_s": gk_again_s,
+        "note": "project.run.RadialDistributionFunction(number_of_configurations=-1) and "
+                "project.run.GreenKuboIonicConductivity(data_range=500), the latter including "
+                "the IonicCurrent transformation the first time; wall time of the call, "
+                "result files included",
+    }
+
+
+def gk_side_measurement(engine, n_frames: int, with_cpu: bool = True) -> dict:
     """BASELINE.json configs[2] in small: ionic current of a 10k-atom velocity block
     (HBM-bound atom reduction) followed by the windowed autocorrelation."""
     data_range = 500
@@ -421,7 +696,7 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         acf, mom = engine.acf_windows(series_dev, 1, 0, n_win, tau, time=time_axis)
         return cur_dev, acf
 
-    _, acf_host = chain_via_host()  # warm-up of both variants; they must agree
+    cur_host, acf_host = chain_via_host()  # warm-up of both variants; they must agree
     _, acf_dev = chain()
     if not np.array_equal(acf_host, acf_dev):
         raise SystemExit("GK chain: device-resident and host-staged series disagree")
@@ -454,14 +729,17 @@ def gk_side_measurement(engine, n_frames: int) -> dict:
         "ms_per_pass": dt * 1e3,
         "ms_per_pass_series_via_host": dt_host * 1e3,
         "roofline_atom_sum": {
-            "kernel": "weighted_sum_kernel<float,4>", "bound": "hbm", "achieved": achieved,
+            "kernel": "weighted_sum_kernel<float, 4, false>", "bound": "hbm", "achieved": achieved,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic_of(recorded("weighted_sum_kernel<float, 4>"))
+            "traffic": traffic_of(recorded("weighted_sum_kernel<float, 4, false>"))
             if n_frames == 100000 else None,
             "avg_launch_ms": avg_ms, "launches": sum_n,
             "algorithmic_bytes_per_launch": bytes_per_launch},
         "acf_slide_kernel_ms": slide_ms / max(slide_n, 1),
     }
+    if with_cpu:
+        out["cpu_baseline"] = gk_cpu_baseline(engine, cur_host.astype(np.float32)[None],
+                                              acf_host, data_range, decay, kick)
 
     # per-atom velocity autocorrelation of one species (GreenKuboDiffusionCoefficients):
     # lag products summed over atoms into a band table, then sliding windows
