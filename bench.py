@@ -630,6 +630,13 @@ def api_measurement(n_frames: int) -> dict:
         ingest_s = time.perf_counter() - t0
         t0 = time.perf_counter()
         rdf = project.run.RadialDistributionFunction(number_of_configurations=-1, plot=False)
+        rdf_first_s = time.perf_counter() - t0
+        # the first calculator call of a process also imports the calculators package
+        # (SciPy: 0.37 s) and loads the kernels' code object; a second run with another
+        # bin count (no cached result) shows the rate of the path itself
+        t0 = time.perf_counter()
+        project.run.RadialDistributionFunction(number_of_configurations=-1, plot=False,
+                                               number_of_bins=NBINS - 240)
         rdf_s = time.perf_counter() - t0
         t0 = time.perf_counter()
         project.run.GreenKuboIonicConductivity(data_range=500, plot=False)
@@ -648,6 +655,7 @@ def api_measurement(n_frames: int) -> dict:
         "ingest_s": ingest_s,
         "rdf_frames_per_s": rdf_frames / rdf_s,
         "rdf_s": rdf_s,
+        "rdf_first_call_s": rdf_first_s,
         "rdf_keys": keys,
         "gk_ionic_frames_per_s": n_frames / gk_s,
         "gk_ionic_s": gk_s,
@@ -655,7 +663,9 @@ def api_measurement(n_frames: int) -> dict:
         "note": "project.run.RadialDistributionFunction(number_of_configurations=-1) and "
                 "project.run.GreenKuboIonicConductivity(data_range=500), the latter including "
                 "the IonicCurrent transformation the first time; wall time of the call, "
-                "result files included",
+                "result files included; rdf_s is a second run with another bin count, "
+                "rdf_first_call_s the process's first calculator call (package import and "
+                "code-object load included, profiles/r03_api_profile.txt)",
     }
 
 
