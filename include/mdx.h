@@ -72,6 +72,11 @@ int mdx_memset(void *dptr, int byte_value, size_t bytes);
  * buffers per device once a host array of 96 MiB or more has been uploaded; this
  * releases both. */
 int mdx_release_cached_memory(void);
+/* How often the library has called the driver's allocators (hipMalloc, hipHostMalloc) and
+ * its own block cache since it was loaded, and the free memory of the current device:
+ * lets a caller verify that a call path allocates nothing. */
+int mdx_allocation_counters(uint64_t *driver_allocations, uint64_t *pool_requests,
+                            uint64_t *device_free_bytes);
 
 /* HIP events recorded on the library stream (the stream every kernel of this
  * library is launched on), for timing kernels from the host side. */

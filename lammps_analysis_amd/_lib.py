@@ -76,6 +76,7 @@ SIGNATURES = {
     "mdx_memcpy_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mdx_memset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
     "mdx_release_cached_memory": (ctypes.c_int, []),
+    "mdx_allocation_counters": (ctypes.c_int, [c_u64_p, c_u64_p, c_u64_p]),
     "mdx_event_create": (ctypes.c_int, [c_void_pp]),
     "mdx_event_record": (ctypes.c_int, [ctypes.c_void_p]),
     "mdx_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_f32_p]),

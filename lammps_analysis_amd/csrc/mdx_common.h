@@ -59,6 +59,8 @@ int get_copy_stream(hipStream_t *stream);
 int pool_acquire(void **ptr, size_t bytes, size_t *capacity, int *device);
 void pool_release(void *ptr, size_t capacity, int device);
 void pool_trim();
+// Counts one call to hipMalloc / hipHostMalloc (mdx_allocation_counters).
+void note_driver_allocation();
 
 struct DeviceBuffer {
   void *ptr = nullptr;

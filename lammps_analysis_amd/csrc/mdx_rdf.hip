@@ -1083,7 +1083,10 @@ int accumulate_host_pipelined(mdx_rdf_s *h, const void *const *species_pos, int 
       p = nullptr;
     }
     h->pinned_bytes = 0;
-    for (void *&p : h->pinned) MDX_HIP(hipHostMalloc(&p, image_bytes, hipHostMallocDefault));
+    for (void *&p : h->pinned) {
+      note_driver_allocation();
+      MDX_HIP(hipHostMalloc(&p, image_bytes, hipHostMallocDefault));
+    }
     h->pinned_bytes = image_bytes;
   }
   DeviceBuffer staged[2];

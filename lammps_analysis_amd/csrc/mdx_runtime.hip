@@ -1,5 +1,7 @@
 // Runtime part of libmdx: error text, device selection, the per-device library
 // stream, raw device memory and event timing.
+#include <atomic>
+
 #include "mdx_common.h"
 
 namespace mdx {
@@ -55,7 +57,14 @@ void trim_device_locked(int dev) {
 }
 }  // namespace
 
+// Calls the library has made to the driver's allocators (device, page-locked host) and
+// every request to its block cache, for tests that must show a call path allocates nothing.
+static std::atomic<uint64_t> g_driver_allocations{0};
+static std::atomic<uint64_t> g_pool_requests{0};
+void note_driver_allocation() { g_driver_allocations.fetch_add(1, std::memory_order_relaxed); }
+
 int pool_acquire(void **ptr, size_t bytes, size_t *capacity, int *device) {
+  g_pool_requests.fetch_add(1, std::memory_order_relaxed);
   int dev = 0;
   MDX_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices)
@@ -81,6 +90,7 @@ int pool_acquire(void **ptr, size_t bytes, size_t *capacity, int *device) {
       return MDX_OK;
     }
   }
+  note_driver_allocation();
   hipError_t e = hipMalloc(ptr, want);
   if (e == hipErrorOutOfMemory) {
     (void)hipGetLastError();
@@ -166,6 +176,7 @@ bool prepare_upload_twins_locked(int dev) {
   UploadTwins &tw = g_upload[dev];
   if (tw.pinned[1] != nullptr) return true;
   for (int b = 0; b < 2; ++b) {
+    note_driver_allocation();
     if (hipHostMalloc(&tw.pinned[b], kUploadChunk, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&tw.sent[b], hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
@@ -367,7 +378,20 @@ int mdx_synchronize(void) {
 int mdx_malloc(void **dptr, size_t bytes) {
   MDX_REQUIRE(dptr != nullptr, "dptr is null");
   *dptr = nullptr;
+  note_driver_allocation();
   MDX_HIP(hipMalloc(dptr, bytes == 0 ? 16 : bytes));
+  return MDX_OK;
+}
+
+int mdx_allocation_counters(uint64_t *driver_allocations, uint64_t *pool_requests,
+                            uint64_t *device_free_bytes) {
+  MDX_REQUIRE(driver_allocations != nullptr && pool_requests != nullptr &&
+                  device_free_bytes != nullptr, "null argument");
+  *driver_allocations = g_driver_allocations.load(std::memory_order_relaxed);
+  *pool_requests = g_pool_requests.load(std::memory_order_relaxed);
+  size_t free_bytes = 0, total_bytes = 0;
+  MDX_HIP(hipMemGetInfo(&free_bytes, &total_bytes));
+  *device_free_bytes = free_bytes;
   return MDX_OK;
 }
 

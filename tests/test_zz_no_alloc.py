@@ -76,3 +76,44 @@ def test_static_entry_point_rejects_rows_beyond_its_array(gpu):
     _lib.check(_lib.load().mdx_weighted_atom_sum_static(dev_x.ptr, _lib.MDX_F32, 0, 5, 3, 1.0,
                                                         out.ptr, 0))
     assert not out.to_numpy().any()
+
+
+def _counters():
+    import ctypes
+    a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(_lib.load().mdx_allocation_counters(ctypes.byref(a), ctypes.byref(b),
+                                                   ctypes.byref(c)))
+    return a.value, b.value, c.value
+
+
+def test_static_entry_point_allocates_nothing(gpu):
+    """After the first call on the device (which looks up the array's address), further
+    calls of any admissible size make no request to the driver's allocators or to the
+    library's block cache, and the device's free memory does not move; the allocating
+    entry point, called between them, does show up in the same counters."""
+    engine = gpu
+    rng = np.random.default_rng(79)
+    shapes = [(300, 2048, 3), (17, 100, 1), (64, 400000, 3), (5, 64, 2)]
+    inputs = []
+    for n_atoms, n_frames, k in shapes:
+        x = engine.DeviceArray.from_numpy(
+            rng.normal(size=(n_atoms, n_frames, k)).astype(np.float32))
+        inputs.append((x, engine.DeviceArray((n_frames, k), np.float64)))
+    _static_sum(engine, inputs[0][0], *shapes[0], 1.0, inputs[0][1])   # first call: set-up
+    engine.synchronize()
+    before = _counters()
+    for _ in range(3):
+        for (x, out), (n_atoms, n_frames, k) in zip(inputs, shapes):
+            _static_sum(engine, x, n_atoms, n_frames, k, 0.5, out)
+            _static_sum(engine, x, n_atoms, n_frames, k, 0.5, out, accumulate=True)
+    engine.synchronize()
+    after = _counters()
+    assert after[0] == before[0], "a static call reached hipMalloc / hipHostMalloc"
+    assert after[1] == before[1], "a static call asked the library's block cache for memory"
+    assert after[2] == before[2], "the device's free memory moved"
+    x, out = inputs[0]
+    np.testing.assert_allclose(out.to_numpy(),
+                               x.to_numpy().astype(np.float64).sum(axis=0), atol=1e-9)
+    # the counters do see the allocating path
+    engine.weighted_atom_sum(x, scalar_weight=1.0, out=out)
+    assert _counters()[1] > after[1]
