@@ -58,7 +58,8 @@ class RdfFastPlan(ctypes.Structure):
                 ("edge_units", ctypes.c_uint32), ("keep_bits", ctypes.c_uint32),
                 ("magic", ctypes.c_float), ("scale", ctypes.c_float),
                 ("s_cut", ctypes.c_float), ("half_box", ctypes.c_float * 3),
-                ("step", ctypes.c_double)]
+                ("step", ctypes.c_double), ("counts_every_pair", ctypes.c_int),
+                ("lds_words", ctypes.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/mdx.h one to one
