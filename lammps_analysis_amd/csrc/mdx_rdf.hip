@@ -550,27 +550,19 @@ __device__ __forceinline__ void fast_tile_loop(
 // LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
-// kDump: the histogram is 2^k words (32 KiB at the benchmark's 3 240 bins), too large for
-// seven blocks of one tile per compute unit, and the loop needs that many waves to hide its
-// dependent chains.  A block therefore holds two tiles' worth of threads sharing one
-// histogram: threads 0..255 take the even frames of a chunk, threads 256..511 the odd ones.
 template <bool kDump>
-__global__ __launch_bounds__(kDump ? 2 * kTile : kTile) void rdf_fast_kernel(
+__global__ __launch_bounds__(kTile) void rdf_fast_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
     int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
     unsigned int *__restrict__ work_counters, RdfParams p, const float *__restrict__ g_thr,
     const int32_t *__restrict__ frame_wrapped, int lds_hist_words,
     unsigned long long *__restrict__ g_hist) {
-  constexpr int kHalves = kDump ? 2 : 1;
-  constexpr int kBlock = kHalves * kTile;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
-  const int thread = threadIdx.x;
-  const int tid = thread & (kTile - 1);   // i-atom within the tile
-  const int half = thread / kTile;        // wave-uniform
-  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + thread * kQueueSlots;
+  const int tid = threadIdx.x;
+  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueSlots;
   uint32_t *claim = reinterpret_cast<uint32_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words) +
-                                                 static_cast<size_t>(kBlock) * kQueueSlots);
+                                                 static_cast<size_t>(kTile) * kQueueSlots);
 
   const float hx = in_vgpr(p.half_box[0]);
   const float hy = in_vgpr(p.half_box[1]);
@@ -584,7 +576,7 @@ __global__ __launch_bounds__(kDump ? 2 * kTile : kTile) void rdf_fast_kernel(
   // Adds the block's LDS counts of `key` to the device histogram and clears them.
   auto flush = [&](int key) {
     unsigned long long *out = g_hist + static_cast<int64_t>(key) * p.nbins;
-    for (int b = thread; b < lds_hist_words; b += kBlock) {
+    for (int b = tid; b < lds_hist_words; b += kTile) {
       const uint32_t v = hist[b];
       if (v != 0u && b < p.nbins) atomicAdd(&out[b], static_cast<unsigned long long>(v));
       hist[b] = 0u;
@@ -607,7 +599,7 @@ __global__ __launch_bounds__(kDump ? 2 * kTile : kTile) void rdf_fast_kernel(
     const uint32_t list_chunks = list_groups * static_cast<uint32_t>(n_pairs);
     if (list_chunks == 0u) continue;
     for (;;) {
-      if (thread == 0) *claim = atomicAdd(&work_counters[list], 1u);
+      if (tid == 0) *claim = atomicAdd(&work_counters[list], 1u);
       __syncthreads();
       const uint32_t chunk = *claim;
       __syncthreads();  // everyone has read the claim before thread 0 writes the next
@@ -625,7 +617,7 @@ __global__ __launch_bounds__(kDump ? 2 * kTile : kTile) void rdf_fast_kernel(
         if (cur_key >= 0) {
           flush(cur_key);
         } else {
-          for (int b = thread; b < lds_hist_words; b += kBlock) hist[b] = 0u;
+          for (int b = tid; b < lds_hist_words; b += kTile) hist[b] = 0u;
           __syncthreads();
         }
         cur_key = tp.key;
@@ -635,7 +627,7 @@ __global__ __launch_bounds__(kDump ? 2 * kTile : kTile) void rdf_fast_kernel(
       const int f_begin = group * frames_per_chunk;
       const int f_end = min(n_frames, f_begin + frames_per_chunk);
       const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
-      for (int f = f_begin + half; f < f_end; f += kHalves) {
+      for (int f = f_begin; f < f_end; ++f) {
         if (frame_wrapped[f] != 2) continue;  // compact frames only, see rdf_fast_setup
         const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
         const float xi = X[slot_i];
@@ -937,7 +929,6 @@ struct mdx_rdf_s {
   DeviceBuffer d_pairs, d_pairs_shard, d_hist, d_thresholds, d_slot_species, d_slot_atom;
   DeviceBuffer d_species_ptr, d_frames, d_packed, d_wrapped, d_counter;
   int fast_blocks = 0;             // persistent grid of the fast kernel
-  int fast_threads = kTile;        // its block size
   size_t fast_lds_bytes = 0;
   int fast_lds_hist_words = 0;
   int shard_rank = 0, shard_count = 1;
@@ -1035,8 +1026,7 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
     MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int) * kWorkLists, stream));
     const int64_t blocks = std::min<int64_t>(h->fast_blocks, std::max<int64_t>(n_chunks, kWorkLists));
 #define MDX_LAUNCH_FAST(DUMP)                                                                \
-  hipLaunchKernelGGL(rdf_fast_kernel<DUMP>, dim3(static_cast<unsigned>(blocks)),            \
-                     dim3(static_cast<unsigned>(h->fast_threads)),                           \
+  hipLaunchKernelGGL(rdf_fast_kernel<DUMP>, dim3(static_cast<unsigned>(blocks)), dim3(kTile), \
                      h->fast_lds_bytes, stream, h->d_packed.as<float>(), h->n_pad, nf,        \
                      frames_per_chunk, static_cast<int>(n_groups),                            \
                      static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),     \
@@ -1320,9 +1310,8 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 
   if (!literal && p.fast_ok) {
     h->fast_lds_hist_words = p.fast_words;
-    h->fast_threads = p.fast_dump ? 2 * kTile : kTile;
     h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
-                        static_cast<size_t>(h->fast_threads) * kQueueSlots + 16;
+                        static_cast<size_t>(kTile) * kQueueSlots + 16;
     const void *fast_fn = p.fast_dump ? reinterpret_cast<const void *>(rdf_fast_kernel<true>)
                                       : reinterpret_cast<const void *>(rdf_fast_kernel<false>);
     if (h->fast_lds_bytes <= 160 * 1024) {
@@ -1332,7 +1321,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
       MDX_HIP(hipFuncGetAttributes(&attr, fast_fn));
       int per_cu = 0;
       if (attr.sharedSizeBytes == 0)  // the histogram then starts at LDS address 0
-        MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fast_fn, h->fast_threads,
+        MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fast_fn, kTile,
                                                              h->fast_lds_bytes));
       hipDeviceProp_t prop;
       MDX_HIP(hipGetDeviceProperties(&prop, h->device));
