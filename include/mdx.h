@@ -183,14 +183,10 @@ int mdx_rdf_read(mdx_rdf_t handle, uint64_t *hist);
  *     bits = float_bits( fma( v_sqrt_f32( fma(m_2, m_2, fma(m_1, m_1, m_0 * m_0)) ),
  *                             scale, magic ) )
  * with magic = 2^k + shift, so that bits & 0x7FFFFF, read as a fixed-point number with
- * frac_bits fraction bits, is the pair's bin position plus shift.  The pair is counted in
- * word (bits & 0x7FFFFF) >> frac_bits of an LDS histogram of lds_words words, of which the
- * first nbins are the result; when bits < keep_bits and the fraction bits are below
- * edge_units it is evaluated again with the literal operations.  With counts_every_pair
- * == 0 a pair with bits >= keep_bits is not counted at all; with counts_every_pair == 1
- * the histogram has a word for every position a pair can take (k covers half the box
- * diagonal in bins, and the NaN of a padding slot lands on word 2^(k-1) >= nbins + 3), so
- * no range test is made.  The counts equal the literal ones as long as the position error stays
+ * frac_bits fraction bits, is the pair's bin position plus shift.  The pair is dropped when
+ * bits >= keep_bits, counted in bin (bits & 0x7FFFFF) >> frac_bits otherwise, and
+ * evaluated again with the literal operations when the fraction bits are below
+ * edge_units.  The counts equal the literal ones as long as the position error stays
  * below shift = edge_units / 2 grid units; this entry point lets a host-side model check
  * that bound against the library's own constants.  usable == 0: the geometry does not
  * admit the kernel (too many bins for the mantissa, degenerate box) and the table kernel
@@ -207,8 +203,6 @@ typedef struct {
   float s_cut;
   float half_box[3];
   double step;
-  int counts_every_pair;
-  int lds_words;
 } mdx_rdf_fast_plan_t;
 int mdx_rdf_fast_plan(const float box[3], float cutoff, int nbins, mdx_rdf_fast_plan_t *plan);
 

@@ -58,8 +58,7 @@ class RdfFastPlan(ctypes.Structure):
                 ("edge_units", ctypes.c_uint32), ("keep_bits", ctypes.c_uint32),
                 ("magic", ctypes.c_float), ("scale", ctypes.c_float),
                 ("s_cut", ctypes.c_float), ("half_box", ctypes.c_float * 3),
-                ("step", ctypes.c_double), ("counts_every_pair", ctypes.c_int),
-                ("lds_words", ctypes.c_int)]
+                ("step", ctypes.c_double)]
 
 
 # name -> (restype, argtypes); mirrors include/mdx.h one to one

@@ -95,8 +95,6 @@ struct RdfParams {
   uint32_t fast_edge_units;  // E: a fraction below E grid units means "near an edge"
   uint32_t fast_keep_bits;   // float bits below this: position < nbins + E grid units
   int fast_ok;               // 0: the bound is too wide for this geometry, do not use
-  int fast_dump;             // 1: the LDS histogram covers every position a pair can take
-  int fast_words;            // LDS words of the histogram (a power of two in dump mode)
 };
 
 // ---------------------------------------------------------------- pack kernel
@@ -433,12 +431,7 @@ __device__ __forceinline__ void fast_resolve_queue(
 }
 
 // One (tile pair, frame) item: lane = i-atom, loop over the j-atoms of the tile.
-// kDump: the LDS histogram has a word for every position a pair of a compact frame can
-// take (and for the NaN of a padding slot), so every pair is counted without asking
-// whether it lies inside the cutoff; the words from nbins on are never read back.  That
-// removes one compare and the exec-mask bracket around each LDS atomic.  The near-edge
-// test is then made once per four pairs, on the smallest of their fractions.
-template <bool kDiag, bool kDump>
+template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
@@ -485,39 +478,18 @@ __device__ __forceinline__ void fast_tile_loop(
       bits[2 * h] = __float_as_uint(t2.x);
       bits[2 * h + 1] = __float_as_uint(t2.y);
     }
-    bool near[4];
-    bool any_near;
-    if (kDump) {
-      uint32_t frac[4];
+    bool keep[4], near[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        frac[u] = bits[u] & frac_mask;
-        if (!kDiag || j0 + u > tid) lds_count((bits[u] >> shift) & addr_mask, one);
-      }
-      const uint32_t lowest = min(min(min(frac[0], frac[1]), frac[2]), frac[3]);
-      any_near = lowest < edge;
-      if (__builtin_expect(any_near, 0)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          near[u] = frac[u] < edge && bits[u] < keep_bits;  // NaN compares above
-          if (kDiag) near[u] = near[u] && (j0 + u > tid);
-        }
-      }
-    } else {
-      bool keep[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        keep[u] = bits[u] < keep_bits;  // a NaN (padding) compares above every position
-        if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
-        near[u] = keep[u] && ((bits[u] & frac_mask) < edge);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (keep[u]) lds_count((bits[u] >> shift) & addr_mask, one);
-      }
-      any_near = near[0] || near[1] || near[2] || near[3];
+    for (int u = 0; u < 4; ++u) {
+      keep[u] = bits[u] < keep_bits;  // a NaN (padding) compares above every position
+      if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
+      near[u] = keep[u] && ((bits[u] & frac_mask) < edge);
     }
-    if (__builtin_expect(any_near, 0)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (keep[u]) lds_count((bits[u] >> shift) & addr_mask, one);
+    }
+    if (__builtin_expect(near[0] || near[1] || near[2] || near[3], 0)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (near[u]) {
@@ -550,7 +522,6 @@ __device__ __forceinline__ void fast_tile_loop(
 // LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
-template <bool kDump>
 __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
     int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
@@ -637,12 +608,11 @@ __global__ __launch_bounds__(kTile) void rdf_fast_kernel(
         const float *yj = xj + n_pad;
         const float *zj = yj + n_pad;
         if (tp.diagonal)
-          fast_tile_loop<true, kDump>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p,
-                                      tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+          fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
         else
-          fast_tile_loop<false, kDump>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr,
-                                       p, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask,
-                                       one);
+          fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+                                hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       }
       __syncthreads();  // the chunk's counts are in before a flush or the next claim
     }
@@ -820,23 +790,25 @@ inline float first_a_reaching(float target, float box) {
 // stored position lies in [pos_lit, pos_lit + 2 shift]: its integer part is the literal
 // bin unless its fraction is below 2 shift, and exactly those pairs are resolved
 // literally.
-// Two layouts of the mantissa share that bound.  "keep": k is the smallest number of
-// integer bits that holds nbins + 2, pairs beyond the cutoff are recognised by a compare
-// and not counted.  "dump": k is large enough for every position a pair of a compact frame
-// can take (each folded component is at most half a box edge, so the distance is at most
-// half the box diagonal), and at least one more than the keep layout's, which puts the NaN
-// of a padding slot (quiet NaN: mantissa bit 22 alone, integer part 2^(k-1)) past the real
-// bins; every pair is then counted without a compare, the words from nbins on are never
-// read.  The dump layout is taken when its histogram fits 64 KiB of LDS and its (coarser)
-// grid still keeps the share of re-evaluated pairs small.
-bool fast_layout(RdfParams &p, int k, double norm_l) {
-  if (k > 15) return false;
+void rdf_fast_setup(RdfParams &p) {
+  p.fast_ok = 0;
+  for (int c = 0; c < 3; ++c) {
+    p.half_box[c] = p.box[c] * 0.5f;
+    if (p.half_box[c] * 2.0f != p.box[c]) return;  // not exact (denormal box)
+    if (p.t_far[c] <= 0.0f) return;                // no frame may use the wrapped form
+  }
+  int k = 1;
+  while ((1 << k) < p.nbins + 3) ++k;
+  if (k > 15) return;
   const int frac_bits = 23 - k;
   const double u = 0x1p-24;
+  const double norm_l = std::sqrt(static_cast<double>(p.box[0]) * p.box[0] +
+                                  static_cast<double>(p.box[1]) * p.box[1] +
+                                  static_cast<double>(p.box[2]) * p.box[2]);
   const double grid = std::ldexp(1.0, -frac_bits);
   const double delta = u * norm_l / p.step + 7.1 * u * (p.nbins + 2.0) + 0.5 * grid + 1e-6;
   const double units = std::ceil(delta / grid);
-  if (2.0 * units > 0.125 / grid) return false;  // more than one pair in eight would be resolved
+  if (2.0 * units > 0.125 / grid) return;  // more than one pair in eight would be resolved
   const uint32_t shift_units = static_cast<uint32_t>(units);
   p.fast_frac_bits = static_cast<uint32_t>(frac_bits);
   p.fast_addr_mask = ((1u << k) - 1u) << 2;
@@ -845,36 +817,6 @@ bool fast_layout(RdfParams &p, int k, double norm_l) {
   p.fast_magic = static_cast<float>(std::ldexp(1.0, k) + shift_units * grid);  // exact
   const float top = static_cast<float>(std::ldexp(1.0, k) + p.nbins);
   p.fast_keep_bits = float_bits(top) + p.fast_edge_units;
-  return true;
-}
-
-void rdf_fast_setup(RdfParams &p) {
-  p.fast_ok = 0;
-  p.fast_dump = 0;
-  for (int c = 0; c < 3; ++c) {
-    p.half_box[c] = p.box[c] * 0.5f;
-    if (p.half_box[c] * 2.0f != p.box[c]) return;  // not exact (denormal box)
-    if (p.t_far[c] <= 0.0f) return;                // no frame may use the wrapped form
-  }
-  const double norm_l = std::sqrt(static_cast<double>(p.box[0]) * p.box[0] +
-                                  static_cast<double>(p.box[1]) * p.box[1] +
-                                  static_cast<double>(p.box[2]) * p.box[2]);
-  int k_keep = 1;
-  while ((1 << k_keep) < p.nbins + 3) ++k_keep;
-  // largest stored position: half the diagonal in bins, the bound's slack, the shift
-  const double pos_max = 0.5 * norm_l / p.step * (1.0 + 1e-5) + 4.0;
-  int k_dump = k_keep + 1;
-  while (k_dump <= 14 && std::ldexp(1.0, k_dump) <= pos_max) ++k_dump;
-  // result-neutral switch for A/B timing: the keep layout
-  const bool want_dump = getenv("MDX_RDF_FAST_KEEP") == nullptr;
-  if (want_dump && k_dump <= 14 && fast_layout(p, k_dump, norm_l)) {
-    p.fast_dump = 1;
-    p.fast_words = 1 << k_dump;
-    p.fast_ok = 1;
-    return;
-  }
-  if (!fast_layout(p, k_keep, norm_l)) return;
-  p.fast_words = (p.nbins + 1 + 3) & ~3;
   p.fast_ok = 1;
 }
 
@@ -1025,16 +967,13 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
     MDX_TRY(h->d_counter.reserve(sizeof(unsigned int) * kWorkLists));
     MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int) * kWorkLists, stream));
     const int64_t blocks = std::min<int64_t>(h->fast_blocks, std::max<int64_t>(n_chunks, kWorkLists));
-#define MDX_LAUNCH_FAST(DUMP)                                                                \
-  hipLaunchKernelGGL(rdf_fast_kernel<DUMP>, dim3(static_cast<unsigned>(blocks)), dim3(kTile), \
-                     h->fast_lds_bytes, stream, h->d_packed.as<float>(), h->n_pad, nf,        \
-                     frames_per_chunk, static_cast<int>(n_groups),                            \
-                     static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),     \
-                     h->d_counter.as<unsigned int>(), h->params, h->d_thresholds.as<float>(), \
-                     h->d_wrapped.as<int32_t>(), h->fast_lds_hist_words,                      \
-                     h->d_hist.as<unsigned long long>())
-    if (h->params.fast_dump) MDX_LAUNCH_FAST(true); else MDX_LAUNCH_FAST(false);
-#undef MDX_LAUNCH_FAST
+    hipLaunchKernelGGL(rdf_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
+                       h->fast_lds_bytes, stream, h->d_packed.as<float>(), h->n_pad, nf,
+                       frames_per_chunk, static_cast<int>(n_groups),
+                       static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),
+                       h->d_counter.as<unsigned int>(), h->params,
+                       h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
+                       h->fast_lds_hist_words, h->d_hist.as<unsigned long long>());
     MDX_HIP(hipGetLastError());
   }
   // One block per (tile pair, frame group).  Frames per block: large enough to amortise
@@ -1309,20 +1248,19 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   }
 
   if (!literal && p.fast_ok) {
-    h->fast_lds_hist_words = p.fast_words;
+    h->fast_lds_hist_words = (nbins + 1 + 3) & ~3;
     h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
                         static_cast<size_t>(kTile) * kQueueSlots + 16;
-    const void *fast_fn = p.fast_dump ? reinterpret_cast<const void *>(rdf_fast_kernel<true>)
-                                      : reinterpret_cast<const void *>(rdf_fast_kernel<false>);
     if (h->fast_lds_bytes <= 160 * 1024) {
-      MDX_HIP(hipFuncSetAttribute(fast_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+      MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_fast_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(h->fast_lds_bytes)));
       hipFuncAttributes attr;
-      MDX_HIP(hipFuncGetAttributes(&attr, fast_fn));
+      MDX_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(rdf_fast_kernel)));
       int per_cu = 0;
       if (attr.sharedSizeBytes == 0)  // the histogram then starts at LDS address 0
-        MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fast_fn, kTile,
-                                                             h->fast_lds_bytes));
+        MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &per_cu, reinterpret_cast<const void *>(rdf_fast_kernel), kTile, h->fast_lds_bytes));
       hipDeviceProp_t prop;
       MDX_HIP(hipGetDeviceProperties(&prop, h->device));
       h->fast_blocks = per_cu * prop.multiProcessorCount;
@@ -1331,9 +1269,9 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
       if (getenv("MDX_RDF_FAST_NO_EDGE")) p.fast_edge_units = 0;
 #endif
       if (getenv("MDX_RDF_DEBUG"))
-        fprintf(stderr, "rdf fast: %s layout, %d blocks/CU, %d CUs, lds %zu, edge units %u of %u\n",
-                p.fast_dump ? "dump" : "keep", per_cu, prop.multiProcessorCount,
-                h->fast_lds_bytes, p.fast_edge_units, 1u << p.fast_frac_bits);
+        fprintf(stderr, "rdf fast: %d blocks/CU, %d CUs, lds %zu, edge units %u of %u\n", per_cu,
+                prop.multiProcessorCount, h->fast_lds_bytes, p.fast_edge_units,
+                1u << p.fast_frac_bits);
       if (const char *env = getenv("MDX_RDF_FAST_BLOCKS")) {
         const int v = atoi(env);
         if (v >= 1) h->fast_blocks = v;
@@ -1396,8 +1334,6 @@ int mdx_rdf_fast_plan(const float box[3], float cutoff, int nbins, mdx_rdf_fast_
     plan->edge_units = p.fast_edge_units;
     plan->keep_bits = p.fast_keep_bits;
     plan->magic = p.fast_magic;
-    plan->counts_every_pair = p.fast_dump;
-    plan->lds_words = p.fast_words;
   }
   return MDX_OK;
 }

@@ -114,13 +114,6 @@ def check_pairs(xi, xj, box, cutoff, nbins, plan):
         assert not bad_drop.any(), (
             f"{int(bad_drop.sum())} pair(s) dropped by the kernel but inside the cutoff "
             f"(sqrt {ulps:+d} ulp), e.g. literal position {pos[bad_drop][0]!r}")
-        if plan.get("counts_every_pair"):
-            # every pair lands in some LDS word: pairs beyond the cutoff past the real
-            # bins, inside the histogram, with the exponent of the magic number intact
-            magic_exponent = np.array([plan["magic"]], F32).view(np.uint32)[0] >> np.uint32(23)
-            assert ((bits >> np.uint32(23)) == magic_exponent).all(), "position left the mantissa"
-            assert (counted < plan["lds_words"]).all()
-            assert (counted[dropped] >= nbins).all(), "a pair beyond the cutoff hit a real bin"
         direct = ~dropped & ~near
         bad_keep = direct & ~kept
         assert not bad_keep.any(), (
@@ -248,5 +241,4 @@ def plan_dict(plan) -> dict:
     return {"usable": int(plan.usable), "frac_bits": int(plan.frac_bits),
             "edge_units": int(plan.edge_units), "keep_bits": int(plan.keep_bits),
             "magic": float(plan.magic), "scale": float(plan.scale), "s_cut": float(plan.s_cut),
-            "half_box": [float(v) for v in plan.half_box], "step": float(plan.step),
-            "counts_every_pair": int(plan.counts_every_pair), "lds_words": int(plan.lds_words)}
+            "half_box": [float(v) for v in plan.half_box], "step": float(plan.step)}
