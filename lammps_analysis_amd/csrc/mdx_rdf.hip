@@ -522,7 +522,13 @@ __device__ __forceinline__ void fast_tile_loop(
 // LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
-__global__ __launch_bounds__(kTile) void rdf_fast_kernel(
+// The loop needs every wave a SIMD can hold to hide its dependent chains (sub, sub, mul,
+// fma, fma, sqrt, fma, shift, and): measured 40.9 k frames/s at four waves per SIMD, 45.5 k at
+// five, 48.7 k at seven, 51.9 k at eight.  Left alone the compiler takes 100 scalar
+// registers, which caps a SIMD at seven waves (800 scalar registers, allocated in
+// sixteens); asked for eight it keeps 72 and moves the rest, set-up values of the outer
+// loops, into lanes of a vector register.
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void rdf_fast_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
     int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
     unsigned int *__restrict__ work_counters, RdfParams p, const float *__restrict__ g_thr,
