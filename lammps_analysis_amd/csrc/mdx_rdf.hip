@@ -16,6 +16,14 @@
 //        rdf_tile_kernel  : one block per (tile pair, frame group); the literal
 //          kernel, the table kernel for frames the fast kernel leaves out.
 //
+// Short cutoffs: every kernel evaluates all pairs of a frame, as the reference does.  When
+// the cutoff is short against the box (mdx_rdf_create decides), the frames are first
+// sorted in space -- rdf_sort_kernel permutes the atoms of every species along a Z-order
+// curve of cells, frame by frame, and records the bounding box of every tile of 256 atoms
+// -- and the fast kernel skips the frames of a tile pair whose boxes are further apart,
+// over the periodic images, than the cutoff plus a margin.  The pair set of a frame does
+// not depend on the order of the atoms within a species, so the counts are unchanged.
+//
 // Three pair functions produce identical bins:
 //   literal : the reference's float32 operations one by one (IEEE divide, rint,
 //             separate multiply/subtract, (x*x+y*y)+z*z, IEEE sqrt, d < cutoff,
@@ -95,6 +103,7 @@ struct RdfParams {
   uint32_t fast_edge_units;  // E: a fraction below E grid units means "near an edge"
   uint32_t fast_keep_bits;   // float bits below this: position < nbins + E grid units
   int fast_ok;               // 0: the bound is too wide for this geometry, do not use
+  float cull_gap2;           // tile pairs with a squared box gap above this hold no pair in reach
 };
 
 // ---------------------------------------------------------------- pack kernel
@@ -148,6 +157,153 @@ __global__ __launch_bounds__(256) void rdf_pack_kernel(
   }
 }
 
+// ---------------------------------------------------------------- sort kernel
+
+struct SortSpecies {
+  int32_t first_slot;  // first slot of the species in a packed frame
+  int32_t used;        // atoms that take part
+  int32_t tiles;       // tiles of 256 slots
+  int32_t cell_bits;   // cells per axis = 1 << cell_bits (at most 4)
+};
+
+constexpr int kSortMaxCells = 4096;
+
+// Z-order index of cell (cx, cy, cz), four bits per axis.
+__device__ __forceinline__ uint32_t morton3(uint32_t cx, uint32_t cy, uint32_t cz) {
+  uint32_t code = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    code |= ((cx >> b) & 1u) << (3 * b);
+    code |= ((cy >> b) & 1u) << (3 * b + 1);
+    code |= ((cz >> b) & 1u) << (3 * b + 2);
+  }
+  return code;
+}
+
+// One block per (species, frame): counting sort of the species' atoms by cell, cells in
+// Z-order, then the bounding box of every tile of the sorted frame.  The order of atoms
+// within a cell is whatever the atomics make it; no result depends on it.  frame_lo holds
+// the frame's smallest coordinate per component (the frame is compact: every coordinate
+// lies within one box length above it), so the cell grid follows a trajectory that is not
+// wrapped into [0, L).  Frames that are not compact are copied unsorted (they go to the
+// table kernel, which skips nothing); their boxes are never read.
+__global__ __launch_bounds__(256) void rdf_sort_kernel(
+    const float *__restrict__ packed, float *__restrict__ sorted, int64_t n_pad, int n_tiles,
+    const SortSpecies *__restrict__ species, const int32_t *__restrict__ frame_wrapped,
+    const float *__restrict__ frame_lo, RdfParams p, float *__restrict__ boxes) {
+  __shared__ uint32_t cell_count[kSortMaxCells];
+  __shared__ uint32_t wave_total[4];
+  const SortSpecies sp = species[blockIdx.x];
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x;
+  const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad + sp.first_slot;
+  float *Y = sorted + static_cast<int64_t>(f) * 3 * n_pad + sp.first_slot;
+  const int slots = sp.tiles * kTile;
+  if (frame_wrapped[f] != 2) {
+    for (int c = 0; c < 3; ++c)
+      for (int i = tid; i < slots; i += 256) Y[c * n_pad + i] = X[c * n_pad + i];
+    return;
+  }
+  const int n_cells = 1 << (3 * sp.cell_bits);
+  const uint32_t per_axis = 1u << sp.cell_bits;
+  for (int i = tid; i < n_cells; i += 256) cell_count[i] = 0u;
+  __syncthreads();
+  float lo[3], scale[3];
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = frame_lo[3 * f + c];
+    scale[c] = static_cast<float>(per_axis) / p.box[c];
+  }
+  auto cell_of = [&](int i) -> uint32_t {
+    uint32_t q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float t = (X[c * n_pad + i] - lo[c]) * scale[c];
+      // NaN and negative values convert to 0; the top is clamped
+      q[c] = min(static_cast<uint32_t>(fmaxf(t, 0.0f)), per_axis - 1u);
+    }
+    return morton3(q[0], q[1], q[2]);
+  };
+  for (int i = tid; i < sp.used; i += 256) atomicAdd(&cell_count[cell_of(i)], 1u);
+  __syncthreads();
+  // exclusive scan of the cell counts: 16 cells per thread at most
+  {
+    const int per_thread = (n_cells + 255) / 256;
+    const int c0 = tid * per_thread;
+    uint32_t sum = 0;
+    for (int k = 0; k < per_thread; ++k)
+      if (c0 + k < n_cells) sum += cell_count[c0 + k];
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t below = __shfl_up(incl, off);
+      if ((tid & 63) >= off) incl += below;
+    }
+    if ((tid & 63) == 63) wave_total[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) base += wave_total[w];
+    for (int k = 0; k < per_thread; ++k)
+      if (c0 + k < n_cells) {
+        const uint32_t n = cell_count[c0 + k];
+        cell_count[c0 + k] = base;
+        base += n;
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < sp.used; i += 256) {
+    const uint32_t dst = atomicAdd(&cell_count[cell_of(i)], 1u);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Y[c * n_pad + dst] = X[c * n_pad + i];
+  }
+  const float nan = __builtin_nanf("");
+  for (int i = sp.used + tid; i < slots; i += 256)
+    for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
+  __syncthreads();  // the block reads back what it wrote
+  // bounding boxes: one wave per tile, four slots per lane; NaN padding is ignored
+  const int first_tile = sp.first_slot / kTile;
+  for (int t = tid >> 6; t < sp.tiles; t += 4) {
+    float mn[3], mx[3];
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = __builtin_inff();
+      mx[c] = -__builtin_inff();
+      for (int k = 0; k < 4; ++k) {
+        const float v = Y[c * n_pad + t * kTile + (tid & 63) + 64 * k];
+        mn[c] = fminf(mn[c], v);
+        mx[c] = fmaxf(mx[c], v);
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        mn[c] = fminf(mn[c], __shfl_xor(mn[c], off));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off));
+      }
+    }
+    if ((tid & 63) == 0) {
+      float *b = boxes + (static_cast<int64_t>(f) * n_tiles + first_tile + t) * 6;
+      for (int c = 0; c < 3; ++c) {
+        b[c] = mn[c];
+        b[3 + c] = mx[c];
+      }
+    }
+  }
+}
+
+// Squared distance between two boxes (lo[3], hi[3]) over the periodic images of a compact
+// frame: per component the smallest gap between the intervals when one of them is moved by
+// -L, 0 or +L (coordinate differences of a compact frame are at most L, so no other image
+// can be the nearest).
+__device__ __forceinline__ float box_gap2(const float *__restrict__ a,
+                                          const float *__restrict__ b, const RdfParams &p) {
+  float sum = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float a0 = a[c], a1 = a[3 + c], b0 = b[c], b1 = b[3 + c], L = p.box[c];
+    const float direct = fmaxf(0.0f, fmaxf(b0 - a1, a0 - b1));
+    const float up = fmaxf(0.0f, fmaxf((b0 + L) - a1, a0 - (b1 + L)));
+    const float down = fmaxf(0.0f, fmaxf((b0 - L) - a1, a0 - (b1 - L)));
+    const float g = fminf(direct, fminf(up, down));
+    sum += g * g;
+  }
+  return sum;
+}
+
 // ------------------------------------------------------------- pair functions
 
 // The reference's sequence of float32 operations, literally.
@@ -173,10 +329,12 @@ __device__ __forceinline__ void pair_literal(float xi, float yi, float zi, float
 // coordinate difference is at most one box length (what a trajectory wrapped into the box
 // gives; the fast kernel's error bound assumes it); 1 = "wrapped", the differences stay
 // below t_far, so the minimum-image shift is at most one box length; 0 = neither.
-// One block per frame; NaN padding is ignored by fminf/fmaxf.
+// One block per frame; NaN padding is ignored by fminf/fmaxf.  frame_lo, if given, receives
+// the frame's smallest coordinate per component.
 __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict__ packed,
                                                          int64_t n_pad, RdfParams p,
-                                                         int32_t *__restrict__ wrapped) {
+                                                         int32_t *__restrict__ wrapped,
+                                                         float *__restrict__ frame_lo) {
   __shared__ float s_min[3][4];
   __shared__ float s_max[3][4];
   const int f = blockIdx.x;
@@ -212,6 +370,7 @@ __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict
       const float extent = mx - mn;
       ok = ok && (extent < p.t_far[c]) && (p.t_far[c] > 0.0f);
       compact = compact && (extent <= p.box[c]);
+      if (frame_lo != nullptr) frame_lo[3 * f + c] = mn;  // origin of the sort's cell grid
     }
     wrapped[f] = ok ? (compact ? 2 : 1) : 0;
   }
@@ -533,7 +692,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
     unsigned int *__restrict__ work_counters, RdfParams p, const float *__restrict__ g_thr,
     const int32_t *__restrict__ frame_wrapped, int lds_hist_words,
-    unsigned long long *__restrict__ g_hist) {
+    unsigned long long *__restrict__ g_hist, const float *__restrict__ boxes, int n_tiles) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   const int tid = threadIdx.x;
@@ -606,6 +765,11 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
       for (int f = f_begin; f < f_end; ++f) {
         if (frame_wrapped[f] != 2) continue;  // compact frames only, see rdf_fast_setup
+        if (boxes != nullptr && !tp.diagonal) {
+          // sorted frames: the two tiles' boxes are further apart than any pair that counts
+          const float *fb = boxes + static_cast<int64_t>(f) * n_tiles * 6;
+          if (box_gap2(fb + tp.tile_i * 6, fb + tp.tile_j * 6, p) > p.cull_gap2) continue;
+        }
         const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
         const float xi = X[slot_i];
         const float yi = X[n_pad + slot_i];
@@ -876,6 +1040,10 @@ struct mdx_rdf_s {
   size_t lds_bytes = 0;
   DeviceBuffer d_pairs, d_pairs_shard, d_hist, d_thresholds, d_slot_species, d_slot_atom;
   DeviceBuffer d_species_ptr, d_frames, d_packed, d_wrapped, d_counter;
+  // short cutoffs: frames sorted in space, tile boxes, tile pairs out of reach skipped
+  bool cull = false;
+  int n_sort_species = 0;
+  DeviceBuffer d_sorted, d_boxes, d_frame_lo, d_sort_species;
   int fast_blocks = 0;             // persistent grid of the fast kernel
   size_t fast_lds_bytes = 0;
   int fast_lds_hist_words = 0;
@@ -924,6 +1092,16 @@ int upload_shard(mdx_rdf_s *h, int rank, int count, hipStream_t stream) {
 
 namespace {
 
+// Buffers of the spatially sorted copy of `frames` packed frames (no-op without culling).
+int reserve_sorted_frames(mdx_rdf_s *h, int64_t frames) {
+  if (!h->cull) return MDX_OK;
+  const size_t n = static_cast<size_t>(frames);
+  MDX_TRY(h->d_sorted.reserve(sizeof(float) * 3 * static_cast<size_t>(h->n_pad) * n));
+  MDX_TRY(h->d_boxes.reserve(sizeof(float) * 6 * static_cast<size_t>(h->n_tiles) * n + 16));
+  MDX_TRY(h->d_frame_lo.reserve(sizeof(float) * 3 * n + 16));
+  return MDX_OK;
+}
+
 // Packs frames [f0, f0 + nf) of the species arrays behind `species_ptr` (or the listed
 // frames) and histograms them with this handle's shard of tile pairs.  d_packed /
 // d_wrapped must hold nf frames.  `packed_done`, if given, is recorded once the
@@ -949,14 +1127,30 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
   MDX_HIP(hipGetLastError());
   if (packed_done != nullptr) MDX_HIP(hipEventRecord(packed_done, stream));
   if (h->n_pairs_shard == 0) return MDX_OK;
+  const bool fast = !literal && h->params.fast_ok != 0 &&
+                    (h->flags & MDX_RDF_TABLE_KERNEL) == 0u && h->fast_blocks > 0;
+  const bool cull = fast && h->cull && h->n_sort_species > 0;
   if (!literal) {
     hipLaunchKernelGGL(rdf_extent_kernel, dim3(static_cast<unsigned>(nf)), dim3(256), 0,
                        stream, h->d_packed.as<float>(), h->n_pad, h->params,
-                       h->d_wrapped.as<int32_t>());
+                       h->d_wrapped.as<int32_t>(), cull ? h->d_frame_lo.as<float>() : nullptr);
     MDX_HIP(hipGetLastError());
   }
-  const bool fast = !literal && h->params.fast_ok != 0 &&
-                    (h->flags & MDX_RDF_TABLE_KERNEL) == 0u && h->fast_blocks > 0;
+  // the image the pair kernels read: the packed frames, or their spatially sorted copy
+  const float *image = h->d_packed.as<float>();
+  const float *boxes = nullptr;
+  if (cull) {
+    KernelTimer sort_timer(MDX_SLOT_RDF_PACK, stream);
+    hipLaunchKernelGGL(rdf_sort_kernel,
+                       dim3(static_cast<unsigned>(h->n_sort_species), static_cast<unsigned>(nf)),
+                       dim3(256), 0, stream, h->d_packed.as<float>(), h->d_sorted.as<float>(),
+                       h->n_pad, static_cast<int>(h->n_tiles), h->d_sort_species.as<SortSpecies>(),
+                       h->d_wrapped.as<int32_t>(), h->d_frame_lo.as<float>(), h->params,
+                       h->d_boxes.as<float>());
+    MDX_HIP(hipGetLastError());
+    image = h->d_sorted.as<float>();
+    boxes = h->d_boxes.as<float>();
+  }
   KernelTimer timer(MDX_SLOT_RDF_TILE, stream);
   if (fast) {
     // chunks of about 10 us of work: short against the launch, long against a claim
@@ -974,12 +1168,13 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
     MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int) * kWorkLists, stream));
     const int64_t blocks = std::min<int64_t>(h->fast_blocks, std::max<int64_t>(n_chunks, kWorkLists));
     hipLaunchKernelGGL(rdf_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
-                       h->fast_lds_bytes, stream, h->d_packed.as<float>(), h->n_pad, nf,
+                       h->fast_lds_bytes, stream, image, h->n_pad, nf,
                        frames_per_chunk, static_cast<int>(n_groups),
                        static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),
                        h->d_counter.as<unsigned int>(), h->params,
                        h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
-                       h->fast_lds_hist_words, h->d_hist.as<unsigned long long>());
+                       h->fast_lds_hist_words, h->d_hist.as<unsigned long long>(), boxes,
+                       static_cast<int>(h->n_tiles));
     MDX_HIP(hipGetLastError());
   }
   // One block per (tile pair, frame group).  Frames per block: large enough to amortise
@@ -1006,7 +1201,7 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
                        h->lds_thr_words, h->d_hist.as<unsigned long long>(), 0);
   } else {
     hipLaunchKernelGGL(rdf_tile_kernel<false>, grid, dim3(kTile), h->lds_bytes, stream,
-                       h->d_packed.as<float>(), h->n_pad, nf, static_cast<int>(fpg),
+                       image, h->n_pad, nf, static_cast<int>(fpg),
                        h->d_pairs_shard.as<TilePair>(), h->params,
                        h->d_thresholds.as<float>(), h->d_wrapped.as<int32_t>(),
                        h->lds_hist_words, h->lds_thr_words,
@@ -1069,6 +1264,7 @@ int accumulate_host_pipelined(mdx_rdf_s *h, const void *const *species_pos, int 
   const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
   MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(block)));
   MDX_TRY(h->d_wrapped.reserve(sizeof(int32_t) * static_cast<size_t>(block)));
+  MDX_TRY(reserve_sorted_frames(h, block));
 
   // One staging image per block parity: all species back to back, each as
   // [atoms][block][3]; a page-locked twin on the host is filled row by row (a row =
@@ -1232,6 +1428,45 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
     }
   }
 
+  std::vector<SortSpecies> sort_table;
+  // Short cutoff against the box: sort the frames in space and skip tile pairs out of
+  // reach.  A tile of 256 atoms of a species with n atoms fills about the 256/n-th part of
+  // the box; skipping can only pay when the cutoff plus such a tile's edge stays well
+  // below half the box.  MDX_RDF_CULL=0/1 overrides the choice (the counts do not change).
+  {
+    const double volume = static_cast<double>(box[0]) * box[1] * box[2];
+    const double shortest = std::min({box[0], box[1], box[2]});
+    bool worth = false;
+    std::vector<SortSpecies> table;
+    for (int s = 0; s < n_species; ++s) {
+      if (tile_count[s] == 0) continue;
+      const int64_t first = strict ? 1 : 0;
+      const int64_t used = n_per_species[s] - first;
+      SortSpecies sp;
+      sp.first_slot = static_cast<int32_t>(tile_first[s] * kTile);
+      sp.used = static_cast<int32_t>(used);
+      sp.tiles = static_cast<int32_t>(tile_count[s]);
+      sp.cell_bits = 1;  // about eight atoms per cell, 16 cells per axis at most
+      while (sp.cell_bits < 4 && (int64_t(1) << (3 * (sp.cell_bits + 1))) * 8 <= used)
+        ++sp.cell_bits;
+      table.push_back(sp);
+      const double tile_edge = std::cbrt(volume * std::min<double>(1.0, double(kTile) / used));
+      if (tile_count[s] >= 8 && cutoff + tile_edge < 0.45 * shortest) worth = true;
+    }
+    if (const char *env = getenv("MDX_RDF_CULL")) worth = atoi(env) != 0;
+    h->cull = worth && !table.empty() && (flags & MDX_RDF_LITERAL_KERNEL) == 0u;
+    if (h->cull) sort_table = table;  // uploaded with the other device tables below
+    // A skipped tile pair must hold no pair the literal rule would count.  Its pairs are
+    // at least the box gap apart; the literal float32 distance is below the true one by
+    // a few 2^-24 of itself plus 2^-24 of the box per component at most, and the gap's
+    // own arithmetic errs by as little: a margin of 1e-5 of cutoff plus box diagonal is
+    // hundreds of times that.
+    const double norm_l = std::sqrt(double(box[0]) * box[0] + double(box[1]) * box[1] +
+                                    double(box[2]) * box[2]);
+    const double reach = static_cast<double>(cutoff) * (1.0 + 1e-5) + 1e-5 * norm_l;
+    p.cull_gap2 = static_cast<float>(reach * reach * (1.0 + 1e-6));
+  }
+
   // LDS budget
   const bool literal = (flags & MDX_RDF_LITERAL_KERNEL) != 0u;
   h->lds_hist_words = (nbins + 3) & ~3;
@@ -1303,6 +1538,12 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
                       sizeof(int32_t) * slot_atom.size(), hipMemcpyHostToDevice));
   }
   MDX_TRY(h->d_species_ptr.alloc(sizeof(void *) * n_species));
+  if (!sort_table.empty()) {
+    h->n_sort_species = static_cast<int>(sort_table.size());
+    MDX_TRY(h->d_sort_species.alloc(sizeof(SortSpecies) * sort_table.size()));
+    MDX_HIP(hipMemcpy(h->d_sort_species.ptr, sort_table.data(),
+                      sizeof(SortSpecies) * sort_table.size(), hipMemcpyHostToDevice));
+  }
 
   // thresholds of the table kernel
   if (!literal) {
@@ -1436,12 +1677,13 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
 
   // frames are processed in chunks bounded by the packed image size
   const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
-  int64_t chunk = static_cast<int64_t>((size_t(2) << 30) / bytes_per_frame);
+  int64_t chunk = static_cast<int64_t>((size_t(h->cull ? 1 : 2) << 30) / bytes_per_frame);
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 32768) chunk = 32768;
   MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(chunk)));
   MDX_TRY(h->d_wrapped.reserve(sizeof(int32_t) * static_cast<size_t>(chunk)));
+  MDX_TRY(reserve_sorted_frames(h, chunk));
   for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = static_cast<int>(std::min<int64_t>(chunk, n_frames - f0));
     MDX_TRY(histogram_frame_block(h, dtype, h->d_species_ptr.as<const void *>(),

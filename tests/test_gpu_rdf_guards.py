@@ -88,3 +88,77 @@ def test_lds_bins_are_flushed_before_they_wrap(gpu, monkeypatch):
     assert expected > 2 ** 32
     assert int(hist[0, 0]) == expected
     assert int(hist.sum()) == expected
+
+
+def _culled_and_not(gpu, monkeypatch, n_per_species, box, cutoff, nbins, pos, strict):
+    out = {}
+    for name, value in (("culled", "1"), ("all_pairs", "0")):
+        monkeypatch.setenv("MDX_RDF_CULL", value)
+        eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins, strict_reference_masks=strict)
+        eng.accumulate(pos)
+        out[name] = eng.read()
+        eng.close()
+    monkeypatch.delenv("MDX_RDF_CULL")
+    return out
+
+
+@pytest.mark.parametrize("case", ["uniform", "rectangular", "faces", "clustered", "shifted",
+                                  "beyond_the_box", "one_sparse_species", "long_cutoff"])
+def test_short_cutoff_path_skips_no_pair(gpu, monkeypatch, case):
+    """Frames sorted in space, tile pairs out of reach skipped (the path short cutoffs take)
+    against the same engine with the skipping off and against the C oracle: uniform and
+    clustered atoms, a rectangular box, atoms exactly on the box faces, a trajectory that
+    is not wrapped into [0, L), frames spread over several boxes (left to the table kernel),
+    a species too small to be sorted into more than one tile, and a cutoff at which
+    nothing can be skipped."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n_per_species, frames = [2900, 1700], 5
+    box = np.array([40.0, 40.0, 40.0], np.float32)
+    cutoff, nbins, strict = np.float32(5.0), 500, True
+    if case == "rectangular":
+        box = np.array([24.0, 40.0, 72.0], np.float32)
+    if case == "one_sparse_species":
+        n_per_species = [4000, 37]
+    if case == "long_cutoff":
+        cutoff, nbins = np.float32(19.9), 1990
+    pos = [(rng.random((n, frames, 3)) * box).astype(np.float32) for n in n_per_species]
+    if case == "faces":
+        for p in pos:
+            p[::3, :, 0] = 0.0
+            p[1::3, :, 0] = box[0]
+            p[::5, :, 2] = np.nextafter(box[2], np.float32(0.0))
+    elif case == "clustered":
+        centres = (rng.random((12, 3)) * box).astype(np.float32)
+        pos = [(centres[rng.integers(0, 12, n)][:, None, :]
+                + rng.normal(scale=1.5, size=(n, frames, 3))).astype(np.float32) % box
+               for n in n_per_species]
+        strict = False
+    elif case == "shifted":
+        for p in pos:
+            p += np.float32(-17.25)          # coordinates in [-17.25, L - 17.25)
+    elif case == "beyond_the_box":
+        pos[0][::9, 1] += np.float32(2.0) * box  # frame 1 spreads over three boxes
+        pos[1][::4, 3] -= np.float32(0.3) * box  # frame 3 a little past a face
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, list(box), cutoff, nbins,
+                            strict=strict)
+    got = _culled_and_not(gpu, monkeypatch, n_per_species, list(box), cutoff, nbins, pos, strict)
+    np.testing.assert_array_equal(got["all_pairs"], ref)
+    np.testing.assert_array_equal(got["culled"], ref)
+    assert ref.sum() > 0
+
+
+def test_short_cutoff_path_is_chosen_by_the_geometry(gpu, monkeypatch):
+    """Without the override the library sorts and skips when the cutoff is short against
+    the box and the species have tiles to skip, and only then; either way the counts are
+    the oracle's.  20 000 atoms, cutoff 6 in a box of 60: most tile pairs are out of reach."""
+    monkeypatch.delenv("MDX_RDF_CULL", raising=False)
+    rng = np.random.default_rng(11)
+    n_per_species, box = [7000, 13000], [60.0, 60.0, 60.0]
+    pos = [(rng.random((n, 2, 3)) * 60.0).astype(np.float32) for n in n_per_species]
+    for cutoff, nbins in ((np.float32(6.0), 600), (np.float32(29.9), 2990)):
+        eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+        eng.accumulate(pos)
+        got = eng.read()
+        eng.close()
+        ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
+        np.testing.assert_array_equal(got, ref)
