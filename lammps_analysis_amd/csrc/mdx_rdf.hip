@@ -167,21 +167,19 @@ struct SortSpecies {
 };
 
 constexpr int kSortMaxCells = 4096;
-
-// Z-order index of cell (cx, cy, cz), four bits per axis.
-__device__ __forceinline__ uint32_t morton3(uint32_t cx, uint32_t cy, uint32_t cz) {
-  uint32_t code = 0;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    code |= ((cx >> b) & 1u) << (3 * b);
-    code |= ((cy >> b) & 1u) << (3 * b + 1);
-    code |= ((cz >> b) & 1u) << (3 * b + 2);
-  }
-  return code;
+// Position of every cell along a Hilbert curve, for grids of 2, 4, 8 and 16 cells per axis
+// back to back (8 + 64 + 512 + 4096 entries); entry = rank of cell (z * g + y) * g + x.
+constexpr int kCurveEntries = 8 + 64 + 512 + 4096;
+__host__ __device__ inline int curve_offset(int cell_bits) {
+  return cell_bits == 1 ? 0 : cell_bits == 2 ? 8 : cell_bits == 3 ? 72 : 584;
 }
 
-// One block per (species, frame): counting sort of the species' atoms by cell, cells in
-// Z-order, then the bounding box of every tile of the sorted frame.  The order of atoms
+// One block per (species, frame): counting sort of the species' atoms by cell, cells along
+// a Hilbert curve (consecutive cells share a face, so 256 consecutive atoms stay together),
+// then the bounding boxes of every tile of the sorted frame and of its four quarters of 64
+// slots.  boxes: per frame [5][n_tiles][...]: n_tiles tile boxes, then 4 n_tiles quarter
+// boxes, six floats each (lowest corner, highest corner); a quarter without atoms gets
+// (+inf, -inf), which is out of everybody's reach.  The order of atoms
 // within a cell is whatever the atomics make it; no result depends on it.  frame_lo holds
 // the frame's smallest coordinate per component (the frame is compact: every coordinate
 // lies within one box length above it), so the cell grid follows a trajectory that is not
@@ -190,7 +188,8 @@ __device__ __forceinline__ uint32_t morton3(uint32_t cx, uint32_t cy, uint32_t c
 __global__ __launch_bounds__(256) void rdf_sort_kernel(
     const float *__restrict__ packed, float *__restrict__ sorted, int64_t n_pad, int n_tiles,
     const SortSpecies *__restrict__ species, const int32_t *__restrict__ frame_wrapped,
-    const float *__restrict__ frame_lo, RdfParams p, float *__restrict__ boxes) {
+    const float *__restrict__ frame_lo, const uint16_t *__restrict__ curve, RdfParams p,
+    float *__restrict__ boxes) {
   __shared__ uint32_t cell_count[kSortMaxCells];
   __shared__ uint32_t wave_total[4];
   const SortSpecies sp = species[blockIdx.x];
@@ -208,6 +207,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   const uint32_t per_axis = 1u << sp.cell_bits;
   for (int i = tid; i < n_cells; i += 256) cell_count[i] = 0u;
   __syncthreads();
+  const uint16_t *rank_of_cell = curve + curve_offset(sp.cell_bits);
   float lo[3], scale[3];
   for (int c = 0; c < 3; ++c) {
     lo[c] = frame_lo[3 * f + c];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       // NaN and negative values convert to 0; the top is clamped
       q[c] = min(static_cast<uint32_t>(fmaxf(t, 0.0f)), per_axis - 1u);
     }
-    return morton3(q[0], q[1], q[2]);
+    return rank_of_cell[(((q[2] << sp.cell_bits) | q[1]) << sp.cell_bits) | q[0]];
   };
   for (int i = tid; i < sp.used; i += 256) atomicAdd(&cell_count[cell_of(i)], 1u);
   __syncthreads();
@@ -258,29 +258,37 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   for (int i = sp.used + tid; i < slots; i += 256)
     for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
   __syncthreads();  // the block reads back what it wrote
-  // bounding boxes: one wave per tile, four slots per lane; NaN padding is ignored
+  // bounding boxes: wave w takes quarter w of every tile (lane = slot); NaN padding is
+  // ignored by fminf / fmaxf
   const int first_tile = sp.first_slot / kTile;
-  for (int t = tid >> 6; t < sp.tiles; t += 4) {
+  float *frame_boxes = boxes + static_cast<int64_t>(f) * 5 * n_tiles * 6;
+  float *quarter_boxes = frame_boxes + static_cast<int64_t>(n_tiles) * 6;
+  for (int t = 0; t < sp.tiles; ++t) {
     float mn[3], mx[3];
     for (int c = 0; c < 3; ++c) {
-      mn[c] = __builtin_inff();
-      mx[c] = -__builtin_inff();
-      for (int k = 0; k < 4; ++k) {
-        const float v = Y[c * n_pad + t * kTile + (tid & 63) + 64 * k];
-        mn[c] = fminf(mn[c], v);
-        mx[c] = fmaxf(mx[c], v);
-      }
+      const float v = Y[c * n_pad + t * kTile + tid];
+      mn[c] = fminf(__builtin_inff(), v);
+      mx[c] = fmaxf(-__builtin_inff(), v);
       for (int off = 32; off > 0; off >>= 1) {
         mn[c] = fminf(mn[c], __shfl_xor(mn[c], off));
         mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off));
       }
     }
     if ((tid & 63) == 0) {
-      float *b = boxes + (static_cast<int64_t>(f) * n_tiles + first_tile + t) * 6;
+      float *b = quarter_boxes + (static_cast<int64_t>(first_tile + t) * 4 + (tid >> 6)) * 6;
       for (int c = 0; c < 3; ++c) {
         b[c] = mn[c];
         b[3 + c] = mx[c];
       }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < sp.tiles; t += 256) {
+    const float *q = quarter_boxes + static_cast<int64_t>(first_tile + t) * 4 * 6;
+    float *b = frame_boxes + static_cast<int64_t>(first_tile + t) * 6;
+    for (int c = 0; c < 3; ++c) {
+      b[c] = fminf(fminf(q[c], q[6 + c]), fminf(q[12 + c], q[18 + c]));
+      b[3 + c] = fmaxf(fmaxf(q[3 + c], q[9 + c]), fmaxf(q[15 + c], q[21 + c]));
     }
   }
 }
@@ -589,23 +597,20 @@ __device__ __forceinline__ void fast_resolve_queue(
   }
 }
 
-// One (tile pair, frame) item: lane = i-atom, loop over the j-atoms of the tile.
+// The j-atoms [j_begin, j_end) of one (tile pair, frame) item: lane = i-atom.  Near-edge
+// pairs are noted in the lane's queue (`count` entries so far) for the caller to resolve.
 template <bool kDiag>
-__device__ __forceinline__ void fast_tile_loop(
-    float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
-    const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
-    float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
-    uint32_t frac_mask, uint32_t one) {
-  const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
-  const int j_end = (j_count + 3) & ~3;  // padding slots hold NaN and are never counted
-  if (j_begin >= j_end) return;
+__device__ __forceinline__ void fast_j_range(
+    int j_begin, int j_end, int &count, float xi, float yi, float zi,
+    const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
+    uint32_t *__restrict__ hist, uint8_t *__restrict__ queue, const float *__restrict__ g_thr,
+    const RdfParams &p, int tid, float hx, float hy, float hz, float scale, float magic,
+    uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
   const uint32_t shift = in_vgpr(p.fast_frac_bits - 2u);
   const uint32_t edge = p.fast_edge_units;
   const uint32_t keep_bits = p.fast_keep_bits;
   const v2f xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
   const v2f scale2 = {scale, scale}, magic2 = {magic, magic};
-  int count = 0;
   float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
   float4 ny = *reinterpret_cast<const float4 *>(yj + j_begin);
   float4 nz = *reinterpret_cast<const float4 *>(zj + j_begin);
@@ -661,6 +666,45 @@ __device__ __forceinline__ void fast_tile_loop(
         fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
                            hist, g_thr, p);
     }
+  }
+}
+
+// One (tile pair, frame) item: all j-atoms of the tile.
+template <bool kDiag>
+__device__ __forceinline__ void fast_tile_loop(
+    float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
+    const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
+    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
+    uint32_t frac_mask, uint32_t one) {
+  const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
+  const int j_end = (j_count + 3) & ~3;  // padding slots hold NaN and are never counted
+  if (j_begin >= j_end) return;
+  int count = 0;
+  fast_j_range<kDiag>(j_begin, j_end, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid,
+                      hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+  fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
+                     g_thr, p);
+}
+
+// The same for a sorted frame and two different tiles: the wave's 64 i-atoms and each
+// quarter of the j-tile have bounding boxes of their own (ibox, jboxes[4]), and a quarter
+// out of the wave's reach is skipped.  The branch is uniform over the wave.
+__device__ __forceinline__ void fast_tile_loop_quarters(
+    float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
+    const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
+    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
+    uint32_t frac_mask, uint32_t one, const float *__restrict__ ibox,
+    const float *__restrict__ jboxes) {
+  const int j_end = (j_count + 3) & ~3;
+  int count = 0;
+  for (int q = 0; q < kTile / 64; ++q) {
+    const int lo = 64 * q;
+    if (lo >= j_end) break;
+    if (box_gap2(ibox, jboxes + 6 * q, p) > p.cull_gap2) continue;
+    fast_j_range<false>(lo, min(j_end, lo + 64), count, xi, yi, zi, xj, yj, zj, hist, queue,
+                        g_thr, p, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
   }
   fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
                      g_thr, p);
@@ -767,7 +811,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (frame_wrapped[f] != 2) continue;  // compact frames only, see rdf_fast_setup
         if (boxes != nullptr && !tp.diagonal) {
           // sorted frames: the two tiles' boxes are further apart than any pair that counts
-          const float *fb = boxes + static_cast<int64_t>(f) * n_tiles * 6;
+          const float *fb = boxes + static_cast<int64_t>(f) * 5 * n_tiles * 6;
           if (box_gap2(fb + tp.tile_i * 6, fb + tp.tile_j * 6, p) > p.cull_gap2) continue;
         }
         const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad;
@@ -780,7 +824,14 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (tp.diagonal)
           fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
                                hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
-        else
+        else if (boxes != nullptr) {
+          const float *quarters = boxes + (static_cast<int64_t>(f) * 5 + 1) * n_tiles * 6;
+          const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+          fast_tile_loop_quarters(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+                                  hx, hy, hz, scale, magic, addr_mask, frac_mask, one,
+                                  quarters + (tp.tile_i * 4 + wave) * 6,
+                                  quarters + tp.tile_j * 4 * 6);
+        } else
           fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
                                 hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       }
@@ -937,6 +988,73 @@ inline float first_a_reaching(float target, float box) {
   return bits_float(hi);
 }
 
+// Rank of every cell of a 2^bits grid along the three-dimensional Hilbert curve
+// (Skilling's transpose form: undo the excess work of the Gray code, then interleave the
+// bits), for bits = 1..4, laid out as curve_offset() says.  Consecutive ranks are cells
+// that share a face; a table that fails this check is replaced by the Z-order, which only
+// costs bounding-box quality.
+std::vector<uint16_t> hilbert_tables() {
+  std::vector<uint16_t> table(kCurveEntries, 0);
+  for (int bits = 1; bits <= 4; ++bits) {
+    const uint32_t g = 1u << bits;
+    uint16_t *out = table.data() + curve_offset(bits);
+    std::vector<int32_t> cell_at(static_cast<size_t>(g) * g * g, -1);
+    for (uint32_t z = 0; z < g; ++z)
+      for (uint32_t y = 0; y < g; ++y)
+        for (uint32_t x = 0; x < g; ++x) {
+          uint32_t X[3] = {x, y, z};
+          const uint32_t M = 1u << (bits - 1);
+          for (uint32_t Q = M; Q > 1; Q >>= 1) {
+            const uint32_t P = Q - 1;
+            for (int i = 0; i < 3; ++i) {
+              if (X[i] & Q) {
+                X[0] ^= P;
+              } else {
+                const uint32_t t = (X[0] ^ X[i]) & P;
+                X[0] ^= t;
+                X[i] ^= t;
+              }
+            }
+          }
+          for (int i = 1; i < 3; ++i) X[i] ^= X[i - 1];
+          uint32_t t = 0;
+          for (uint32_t Q = M; Q > 1; Q >>= 1)
+            if (X[2] & Q) t ^= Q - 1;
+          for (int i = 0; i < 3; ++i) X[i] ^= t;
+          uint32_t rank = 0;
+          for (int j = bits - 1; j >= 0; --j)
+            for (int i = 0; i < 3; ++i) rank = (rank << 1) | ((X[i] >> j) & 1u);
+          const uint32_t cell = (z * g + y) * g + x;
+          out[cell] = static_cast<uint16_t>(rank);
+          if (rank < cell_at.size()) cell_at[rank] = static_cast<int32_t>(cell);
+        }
+    bool ok = true;
+    for (size_t r = 0; r < cell_at.size() && ok; ++r) {
+      if (cell_at[r] < 0) ok = false;
+      if (ok && r > 0) {
+        const int a = cell_at[r - 1], b = cell_at[r];
+        const int dx = std::abs(int(a % g) - int(b % g));
+        const int dy = std::abs(int(a / g % g) - int(b / g % g));
+        const int dz = std::abs(int(a / (g * g)) - int(b / (g * g)));
+        ok = dx + dy + dz == 1;
+      }
+    }
+    if (!ok) {
+      for (uint32_t cell = 0; cell < g * g * g; ++cell) {
+        const uint32_t x = cell % g, y = cell / g % g, z = cell / (g * g);
+        uint32_t code = 0;
+        for (int b = 0; b < bits; ++b) {
+          code |= ((x >> b) & 1u) << (3 * b);
+          code |= ((y >> b) & 1u) << (3 * b + 1);
+          code |= ((z >> b) & 1u) << (3 * b + 2);
+        }
+        out[cell] = static_cast<uint16_t>(code);
+      }
+    }
+  }
+  return table;
+}
+
 // Parameters of the fast kernel and the bound that makes it exact.
 //
 // For a pair in a compact frame (|r_c| <= L_c in every component) let pos_lit =
@@ -1043,7 +1161,7 @@ struct mdx_rdf_s {
   // short cutoffs: frames sorted in space, tile boxes, tile pairs out of reach skipped
   bool cull = false;
   int n_sort_species = 0;
-  DeviceBuffer d_sorted, d_boxes, d_frame_lo, d_sort_species;
+  DeviceBuffer d_sorted, d_boxes, d_frame_lo, d_sort_species, d_curve;
   int fast_blocks = 0;             // persistent grid of the fast kernel
   size_t fast_lds_bytes = 0;
   int fast_lds_hist_words = 0;
@@ -1097,7 +1215,7 @@ int reserve_sorted_frames(mdx_rdf_s *h, int64_t frames) {
   if (!h->cull) return MDX_OK;
   const size_t n = static_cast<size_t>(frames);
   MDX_TRY(h->d_sorted.reserve(sizeof(float) * 3 * static_cast<size_t>(h->n_pad) * n));
-  MDX_TRY(h->d_boxes.reserve(sizeof(float) * 6 * static_cast<size_t>(h->n_tiles) * n + 16));
+  MDX_TRY(h->d_boxes.reserve(sizeof(float) * 6 * 5 * static_cast<size_t>(h->n_tiles) * n + 16));
   MDX_TRY(h->d_frame_lo.reserve(sizeof(float) * 3 * n + 16));
   return MDX_OK;
 }
@@ -1145,8 +1263,8 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
                        dim3(static_cast<unsigned>(h->n_sort_species), static_cast<unsigned>(nf)),
                        dim3(256), 0, stream, h->d_packed.as<float>(), h->d_sorted.as<float>(),
                        h->n_pad, static_cast<int>(h->n_tiles), h->d_sort_species.as<SortSpecies>(),
-                       h->d_wrapped.as<int32_t>(), h->d_frame_lo.as<float>(), h->params,
-                       h->d_boxes.as<float>());
+                       h->d_wrapped.as<int32_t>(), h->d_frame_lo.as<float>(),
+                       h->d_curve.as<uint16_t>(), h->params, h->d_boxes.as<float>());
     MDX_HIP(hipGetLastError());
     image = h->d_sorted.as<float>();
     boxes = h->d_boxes.as<float>();
@@ -1543,6 +1661,10 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
     MDX_TRY(h->d_sort_species.alloc(sizeof(SortSpecies) * sort_table.size()));
     MDX_HIP(hipMemcpy(h->d_sort_species.ptr, sort_table.data(),
                       sizeof(SortSpecies) * sort_table.size(), hipMemcpyHostToDevice));
+    const std::vector<uint16_t> curve = hilbert_tables();
+    MDX_TRY(h->d_curve.alloc(sizeof(uint16_t) * curve.size()));
+    MDX_HIP(hipMemcpy(h->d_curve.ptr, curve.data(), sizeof(uint16_t) * curve.size(),
+                      hipMemcpyHostToDevice));
   }
 
   // thresholds of the table kernel
