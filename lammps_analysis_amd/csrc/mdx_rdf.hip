@@ -1547,10 +1547,13 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   }
 
   std::vector<SortSpecies> sort_table;
-  // Short cutoff against the box: sort the frames in space and skip tile pairs out of
-  // reach.  A tile of 256 atoms of a species with n atoms fills about the 256/n-th part of
-  // the box; skipping can only pay when the cutoff plus such a tile's edge stays well
-  // below half the box.  MDX_RDF_CULL=0/1 overrides the choice (the counts do not change).
+  // Short cutoff against the box: sort the frames in space and skip what is out of reach
+  // (whole tile pairs, and quarters of a j-tile per wave).  The 64 atoms of a wave or of a
+  // quarter, of a species with n atoms, fill about the 64/n-th part of the box; skipping can
+  // only pay when the cutoff plus the edge of such a group stays well below half the box
+  // (measured: 10k-atom melt in a 65 box, cutoff 10: 74 k instead of 57 k frames/s; 100k-atom
+  // water box, cutoff 10: 4.4 k instead of 0.6 k).  MDX_RDF_CULL=0/1 overrides the choice
+  // (the counts do not change).
   {
     const double volume = static_cast<double>(box[0]) * box[1] * box[2];
     const double shortest = std::min({box[0], box[1], box[2]});
@@ -1568,8 +1571,8 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
       while (sp.cell_bits < 4 && (int64_t(1) << (3 * (sp.cell_bits + 1))) * 8 <= used)
         ++sp.cell_bits;
       table.push_back(sp);
-      const double tile_edge = std::cbrt(volume * std::min<double>(1.0, double(kTile) / used));
-      if (tile_count[s] >= 8 && cutoff + tile_edge < 0.45 * shortest) worth = true;
+      const double group_edge = std::cbrt(volume * std::min<double>(1.0, 64.0 / used));
+      if (tile_count[s] >= 8 && cutoff + group_edge < 0.45 * shortest) worth = true;
     }
     if (const char *env = getenv("MDX_RDF_CULL")) worth = atoi(env) != 0;
     h->cull = worth && !table.empty() && (flags & MDX_RDF_LITERAL_KERNEL) == 0u;
