@@ -1346,13 +1346,14 @@ struct EventPairGuard {
 // page-locked image.  A block of 10 000 atoms x 256 frames is 30 MB in 10 000 pieces; one
 // host thread moves that in about the time the GPU needs for the block, so large
 // gathers are split over a few threads.
-void gather_rows(char *dst, const char *src, int64_t n_rows, size_t row, size_t pitch) {
+void gather_rows(char *dst, const char *src, int64_t n_rows, size_t row, size_t pitch,
+                 unsigned max_threads = 4) {
   auto part = [=](int64_t a0, int64_t a1) {
     for (int64_t a = a0; a < a1; ++a)
       memcpy(dst + static_cast<size_t>(a) * row, src + static_cast<size_t>(a) * pitch, row);
   };
   const size_t bytes = static_cast<size_t>(n_rows) * row;
-  unsigned n_threads = bytes >= (size_t(4) << 20) ? 4u : 1u;
+  unsigned n_threads = bytes >= (size_t(4) << 20) ? max_threads : 1u;
   const unsigned hw = std::thread::hardware_concurrency();
   if (hw != 0 && hw < n_threads) n_threads = hw;
   if (n_threads <= 1 || n_rows < 64) {
@@ -1379,6 +1380,15 @@ int accumulate_host_pipelined(mdx_rdf_s *h, const void *const *species_pos, int 
   int64_t block = n_frames / 4;
   if (block < 64) block = 64;
   if (block > 512) block = 512;
+  if (const char *env = getenv("MDX_RDF_HOST_BLOCK")) {  // A/B timing of the staging block
+    const int v = atoi(env);
+    if (v >= 16 && v <= 16384) block = v;
+  }
+  unsigned gather_threads = 4;
+  if (const char *env = getenv("MDX_RDF_GATHER_THREADS")) {
+    const int v = atoi(env);
+    if (v >= 1 && v <= 64) gather_threads = static_cast<unsigned>(v);
+  }
   const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
   MDX_TRY(h->d_packed.reserve(bytes_per_frame * static_cast<size_t>(block)));
   MDX_TRY(h->d_wrapped.reserve(sizeof(int32_t) * static_cast<size_t>(block)));
@@ -1447,7 +1457,7 @@ int accumulate_host_pipelined(mdx_rdf_s *h, const void *const *species_pos, int 
       const char *src = static_cast<const char *>(species_pos[s]) + f0 * 3 * elem;
       char *dst = twin + offset[s];
       const size_t pitch = static_cast<size_t>(frame_stride) * 3 * elem;
-      gather_rows(dst, src, h->n_per_species[s], row, pitch);
+      gather_rows(dst, src, h->n_per_species[s], row, pitch, gather_threads);
     }
     MDX_HIP(hipMemcpyAsync(staged[b].ptr, twin, image_bytes, hipMemcpyHostToDevice,
                            copy_stream));
