@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import lammps_analysis_amd as mds
+from lammps_analysis_amd import engine
 from lammps_analysis_amd.database.mdsuite_properties import mdsuite_properties
 from lammps_analysis_amd.database.simulation_database import (SpeciesInfo,
                                                               TrajectoryChunkData,
@@ -184,7 +185,7 @@ def test_rdf_calculator_matches_oracle_and_caches(gpu, tmp_path):
                                       np.asarray(ref_full[key]["y"])[1:])
 
 
-def test_rdf_calculator_streams_long_frame_runs_from_the_store(gpu, tmp_path):
+def test_rdf_calculator_streams_long_frame_runs_from_the_store(gpu, tmp_path, monkeypatch):
     """A dense sample over a few hundred frames: runs of consecutive frames are streamed
     from the store's memory maps, a strided dense sample goes by frame list, a sparse one
     through the batch loop; all three agree with the oracle count for count."""
@@ -197,8 +198,25 @@ def test_rdf_calculator_streams_long_frame_runs_from_the_store(gpu, tmp_path):
                "Cl": {mdsuite_properties.positions: pos_cl}}, n_step, box_l=[box] * 3)
     stored = [np.swapaxes(pos_na, 0, 1).astype(np.float32),
               np.swapaxes(pos_cl, 0, 1).astype(np.float32)]
-    for n_cfg in (-1, 150, 20):   # two runs of ~150 frames / every other frame / sparse
+    calls = []
+    plain_accumulate = engine.RdfEngine.accumulate
+
+    def recording(self, positions, **kwargs):
+        calls.append(kwargs)
+        return plain_accumulate(self, positions, **kwargs)
+
+    monkeypatch.setattr(engine.RdfEngine, "accumulate", recording)
+    # 298 consecutive frames and the last one alone / every other frame / one in 15 /
+    # sparse (fewer than one frame in 32: the batch loop)
+    for n_cfg, route in ((-1, "frame_range"), (150, "frames"), (20, "frames"), (5, None)):
+        calls.clear()
         got = exp.run.RadialDistributionFunction(number_of_configurations=n_cfg, plot=False)
+        if route is None:
+            assert all("frames" not in c and "frame_range" not in c for c in calls)
+        else:
+            assert calls and all(c.get(route) is not None for c in calls), calls
+        if n_cfg == -1:
+            assert [c["frame_range"] for c in calls] == [(0, 298), (299, 300)]
         ref, _ = orc_rdf.radial_distribution_function(
             stored, ["Na", "Cl"], {"Na": 37, "Cl": 45}, [box] * 3, mds.units.METAL.length,
             number_of_configurations=n_cfg)
