@@ -380,6 +380,8 @@ def main() -> None:
             result["gk_acf_frames_per_s"] = result["gk_acf"]["frames_per_s"]
         if args.flux_atoms > 0:
             result["flux_reductions"] = flux_side_measurement(engine, args.flux_atoms, 100000)
+            result["transformations"] = transformation_side_measurement(
+                engine, args.flux_atoms, 100000)
         if not args.skip_host_input:
             result["host_input"] = host_input_measurement(engine, min(fps, 1024))
         if args.api_frames > 0:
@@ -577,6 +579,80 @@ def flux_side_measurement(engine, n_atoms: int, n_frames: int) -> dict:
     for arr in (stress, vel, ke, pe):
         arr.free()
     return out
+
+
+def transformation_side_measurement(engine, n_atoms: int, n_frames: int) -> dict:
+    """The per-atom coordinate transformations and the Kinaci heat current: single passes
+    over ``[atoms][frames][3]`` float32 arrays (read + write, or read only for the heat
+    current), timed with device-resident input.  The unwrapped input is a slow
+    Ornstein-Uhlenbeck walk (0.09 per frame, box 65), wrapped into the box on the device,
+    so that an atom crosses a face about once in a thousand frames, as in a trajectory."""
+    box = [BOX] * 3
+    walk = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    walk.fill_langevin(seed=900, decay=1.0 - 1e-5, kick=20.0 * (2e-5) ** 0.5)
+    wrapped = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    engine.map_coordinates(engine.MAP_WRAP, walk, box, out=wrapped)
+    out = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    cell = n_atoms * n_frames * 4
+    cases = {
+        "unwrap_coordinates": (lambda: engine.unwrap_coordinates(wrapped, box, out=out),
+                               6 * cell, "transform", "unwrap_stream_kernel<4>",
+                               "3 words read + 3 written per atom and frame"),
+        "wrap_coordinates": (lambda: engine.map_coordinates(engine.MAP_WRAP, walk, box, out=out),
+                             6 * cell, "transform", "map_kernel<0, float, float>",
+                             "3 words read + 3 written"),
+        "scale_coordinates": (lambda: engine.map_coordinates(engine.MAP_SCALE, walk, box,
+                                                             out=out),
+                              6 * cell, "transform", "map_kernel<2, float, float>",
+                              "3 words read + 3 written"),
+        "velocity_from_positions": (lambda: engine.map_coordinates(
+            engine.MAP_VELOCITY, walk, [0.002, 0, 0], out=out), 6 * cell, "transform",
+            "map_kernel<4, float, float>", "3 words read + 3 written"),
+    }
+    result = {"workload": f"{n_atoms} atoms x {n_frames} frames, float32 in and out, device "
+                          "resident"}
+    reps = 3
+
+    def timed(fn, slot):
+        fn()  # warm-up
+        engine.profile_enable(True)
+        engine.profile_reset()
+        for _ in range(reps):
+            fn()
+        engine.synchronize()
+        engine.profile_enable(False)
+        ms, launches = engine.profile_query(slot)
+        return ms / max(launches, 1), launches
+
+    def entry(kernel, avg, launches, nbytes, what):
+        achieved = nbytes / (avg * 1e-3) / 1e9
+        return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "avg_launch_ms": avg, "launches": launches,
+                "algorithmic_bytes_per_launch": nbytes, "algorithmic_bytes": what}
+
+    for name, (fn, nbytes, slot, kernel, what) in cases.items():
+        avg, launches = timed(fn, slot)
+        result[name] = entry(kernel, avg, launches, nbytes, what)
+    walk.free()
+    out.free()
+    # Kinaci heat current: position, velocity, force (3 words each) and the potential
+    # energy (1) per atom and frame; two launches (block totals of force.velocity, then the
+    # scan with its offsets and the atom reduction) fetch 16 words for these 10
+    vel = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    force = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
+    pe = engine.DeviceArray((n_atoms, n_frames, 1), np.float32)
+    for seed, arr in enumerate((vel, force, pe)):
+        arr.fill_uniform(seed=910 + seed, lo=-1.0, hi=1.0)
+    avg, launches = timed(lambda: engine.kinaci_heat_current(wrapped, vel, force, pe, 0.002),
+                          "flux")
+    result["kinaci_heat_current"] = entry(
+        "kinaci_kernel<float, false> + kinaci_offsets_kernel + kinaci_kernel<float, true>", avg,
+        launches, 10 * cell, "position 3 + velocity 3 + force 3 + potential energy 1; the two "
+                             "passes fetch 16 words for these 10")
+    for arr in (wrapped, vel, force, pe):
+        arr.free()
+    return result
 
 
 def api_measurement(n_frames: int) -> dict:

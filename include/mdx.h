@@ -97,8 +97,9 @@ int mdx_event_destroy(mdx_event_t ev);
 #define MDX_SLOT_ACF_PARTIAL 3
 #define MDX_SLOT_ACF_FINISH 4
 #define MDX_SLOT_MSD 5
-#define MDX_SLOT_FLUX 6 /* momentum / thermal flux, energy-weighted sum */
-#define MDX_NUM_SLOTS 7
+#define MDX_SLOT_FLUX 6 /* momentum / thermal flux, energy-weighted sum, Kinaci heat current */
+#define MDX_SLOT_TRANSFORM 7 /* unwrap and element-wise coordinate maps */
+#define MDX_NUM_SLOTS 8
 int mdx_profile_enable(int on);
 int mdx_profile_reset(void);
 int mdx_profile_query(int slot, double *total_ms, int64_t *launches);

@@ -815,7 +815,10 @@ int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
                        n_frames, plan.atoms_per_chunk, dt, d_carry.as<double>(),              \
                        totals.as<double>(), partial.as<double>());                            \
   } while (0)
-  if (dtype == MDX_F32) MDX_KINACI(float); else MDX_KINACI(double);
+  {
+    KernelTimer timer(MDX_SLOT_FLUX, stream);
+    if (dtype == MDX_F32) MDX_KINACI(float); else MDX_KINACI(double);
+  }
 #undef MDX_KINACI
   MDX_HIP(hipGetLastError());
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, n_cols, out, out_location,

@@ -660,7 +660,7 @@ def msd_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: in
 # ------------------------------------------------------------------ profiling
 
 SLOTS = {"rdf_pack": 0, "rdf_tile": 1, "atom_sum": 2, "acf_partial": 3, "acf_finish": 4,
-         "msd": 5, "flux": 6}
+         "msd": 5, "flux": 6, "transform": 7}
 
 
 def profile_enable(on: bool = True) -> None:

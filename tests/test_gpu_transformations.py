@@ -62,6 +62,57 @@ def test_unwrap_matches_oracle_across_batches(gpu, dtype, shape):
         np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
 
 
+@pytest.mark.parametrize("n_frames", [1, 3, 4, 255, 256, 257, 260, 511, 512, 516, 1027, 2048])
+def test_unwrap_stream_kernel_matches_oracle(gpu, monkeypatch, n_frames):
+    """float32 to float32 with many atoms takes the streaming kernel (wave = atom): frame
+    counts around its step (256 frames), rows that are and are not 16-byte aligned, the
+    carry across three batches, a box image and a last position handed in, and atom counts
+    that leave waves of the last block without an atom."""
+    monkeypatch.setenv("MDX_UNWRAP_STREAM_MIN_ATOMS", "1")
+    rng = np.random.default_rng(100 + n_frames)
+    for n_atoms in (1, 6, 9):
+        wrapped, _ = _walk(rng, n_atoms, n_frames, BOX, step=0.3)
+        wrapped = wrapped.astype(np.float32)
+        got, carry = gpu.unwrap_coordinates(wrapped, BOX, out_dtype=np.float32)
+        ref, ref_carry = ort.unwrap_coordinates(wrapped, BOX)
+        np.testing.assert_array_equal(got, ref.astype(np.float32))
+        np.testing.assert_array_equal(carry["last_pos"], ref_carry["last_pos"])
+        np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+        carry = {"last_pos": rng.random((n_atoms, 3)) * BOX,
+                 "last_image_box": rng.integers(-3, 4, size=(n_atoms, 3)).astype(np.float64)}
+        ref_carry = {k: v.copy() for k, v in carry.items()}
+        edges = [0, n_frames // 3, 2 * n_frames // 3, n_frames]
+        for a, b in zip(edges[:-1], edges[1:]):
+            if a == b:
+                continue
+            piece = np.ascontiguousarray(wrapped[:, a:b])
+            got, carry = gpu.unwrap_coordinates(piece, BOX, carry=carry, out_dtype=np.float32)
+            ref, ref_carry = ort.unwrap_coordinates(piece, BOX, carryover=ref_carry)
+            np.testing.assert_array_equal(got, ref.astype(np.float32))
+            np.testing.assert_array_equal(carry["last_pos"], ref_carry["last_pos"])
+            np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+
+
+def test_unwrap_stream_kernel_exact_rounding_cases(gpu, monkeypatch):
+    """Differences that are exact half-integer multiples of the box (ties round to even),
+    jumps of many boxes, and frames that do not move: the quick rejection of small
+    quotients and the exact path behind it agree with the float64 expressions."""
+    monkeypatch.setenv("MDX_UNWRAP_STREAM_MIN_ATOMS", "1")
+    box = np.array([2.0, 4.0, 0.5])
+    steps = np.array([0.0, 0.5, -0.5, 1.5, -1.5, 2.5, 0.49, -0.49, 0.51, -0.51, 1000.5, -77.0,
+                      0.4999999, 0.5000001, 1e-30])
+    rng = np.random.default_rng(5)
+    picks = rng.integers(0, len(steps), size=(7, 600, 3))
+    free = np.cumsum(steps[picks] * box, axis=1).astype(np.float32)
+    got, carry = gpu.unwrap_coordinates(free, box, out_dtype=np.float32)
+    ref, ref_carry = ort.unwrap_coordinates(free, box)
+    np.testing.assert_array_equal(got, ref.astype(np.float32))
+    np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+    monkeypatch.setenv("MDX_UNWRAP_STREAM_MIN_ATOMS", "1000000")
+    other, _ = gpu.unwrap_coordinates(free, box, out_dtype=np.float32)
+    np.testing.assert_array_equal(got, other)
+
+
 def test_unwrap_device_resident_input_and_output(gpu):
     rng = np.random.default_rng(22)
     wrapped, _ = _walk(rng, 40, 700, BOX)
