@@ -313,7 +313,14 @@ def main() -> None:
             "frac_of_issue_bound": pairs_per_s_kernel / issue_bound,
         })
     if "SQ_INSTS_VALU" in pmc:
-        slots = pairs_per_frame * frames_per_launch / 64.0
+        # wave-level pair evaluations of a frame: species are padded to tiles of 256 slots
+        # (first atom left out under the strict masks); a pair of different tiles costs
+        # 256 j-atoms for each of its four waves, a tile paired with itself 256 + 192 + 128
+        # + 64 (a wave skips the j-atoms below its first lane)
+        tiles = [-(-(n - 1) // 256) for n in n_per_species]
+        slots_per_frame = sum(t * (t - 1) // 2 * 1024 + t * 640 for t in tiles) + sum(
+            tiles[a] * tiles[b] * 1024 for a in range(len(tiles)) for b in range(a + 1, len(tiles)))
+        slots = slots_per_frame * frames_per_launch * share
         valu["valu_insts_per_launch_pmc"] = pmc["SQ_INSTS_VALU"]
         valu["valu_insts_per_wave_pair_slot_pmc"] = pmc["SQ_INSTS_VALU"] / slots
         valu["cycles_per_wave_pair_slot_at_2p4GHz"] = (tile_avg_ms * 1e-3 * 2.4e9 * 1024) / slots
@@ -624,10 +631,16 @@ def transformation_side_measurement(engine, n_atoms: int, n_frames: int) -> dict
         ms, launches = engine.profile_query(slot)
         return ms / max(launches, 1), launches
 
-    def entry(kernel, avg, launches, nbytes, what):
+    on_record = (n_atoms, n_frames) == (5000, 100000)
+
+    def entry(kernel, avg, launches, nbytes, what, kernels_on_record=None):
         achieved = nbytes / (avg * 1e-3) / 1e9
+        traffic = None
+        if on_record:
+            parts = [traffic_of(recorded(k)) for k in (kernels_on_record or [kernel])]
+            traffic = sum(parts) if all(p is not None for p in parts) else None
         return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "avg_launch_ms": avg, "launches": launches,
                 "algorithmic_bytes_per_launch": nbytes, "algorithmic_bytes": what}
 
@@ -649,7 +662,9 @@ def transformation_side_measurement(engine, n_atoms: int, n_frames: int) -> dict
     result["kinaci_heat_current"] = entry(
         "kinaci_kernel<float, false> + kinaci_offsets_kernel + kinaci_kernel<float, true>", avg,
         launches, 10 * cell, "position 3 + velocity 3 + force 3 + potential energy 1; the two "
-                             "passes fetch 16 words for these 10")
+                             "passes fetch 16 words for these 10",
+        kernels_on_record=["kinaci_kernel<float, false>", "kinaci_offsets_kernel",
+                           "kinaci_kernel<float, true>"])
     for arr in (wrapped, vel, force, pe):
         arr.free()
     return result

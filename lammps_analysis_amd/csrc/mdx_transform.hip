@@ -475,6 +475,18 @@ __global__ __launch_bounds__(kThreads) void map_kernel(const TIn *__restrict__ x
       t = t_first + (u * kUnitStride + d_first) / 3;
       if (t >= n_frames) t %= n_frames;
     }
+    // forward differences reach three words past the unit: the next lane's first words
+    // (the wave's last lane and the array's last units read them from memory)
+    TIn beyond[3] = {TIn(0), TIn(0), TIn(0)};
+    if (OP == MDX_MAP_VELOCITY && full) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) beyond[i] = __shfl_down(in[u][i], 1);
+      if ((threadIdx.x & 63) == 63 || e0 + 2 * kPerThread > n_elements) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          beyond[i] = (e0 + kPerThread + i < n_elements) ? x[e0 + kPerThread + i] : TIn(0);
+      }
+    }
     TOut res[kPerThread];
 #pragma unroll
     for (int j = 0; j < kPerThread; ++j) {
@@ -494,9 +506,10 @@ __global__ __launch_bounds__(kThreads) void map_kernel(const TIn *__restrict__ x
         const int64_t e = e0 + j;
         if (e < n_elements) {
           if (t + 1 < n_frames) {
-            const double next = (j + 3 < kPerThread && full)
-                                    ? static_cast<double>(in[u][j + 3])
-                                    : static_cast<double>(x[e + 3]);
+            const double next =
+                !full ? static_cast<double>(x[e + 3])
+                      : static_cast<double>(j + 3 < kPerThread ? in[u][j + 3]
+                                                               : beyond[(j + 3) % kPerThread]);
             r = (next - v) / par.v[0];
           } else {
             r = (v - static_cast<double>(x[e - 3])) / par.v[0];
