@@ -650,8 +650,8 @@ def transformation_side_measurement(engine, n_atoms: int, n_frames: int) -> dict
     walk.free()
     out.free()
     # Kinaci heat current: position, velocity, force (3 words each) and the potential
-    # energy (1) per atom and frame; two launches (block totals of force.velocity, then the
-    # scan with its offsets and the atom reduction) fetch 16 words for these 10
+    # energy (1) per atom and frame; the streaming pass reads them once and a weighted column
+    # sum reads the positions again (13 words fetched for these 10)
     vel = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
     force = engine.DeviceArray((n_atoms, n_frames, 3), np.float32)
     pe = engine.DeviceArray((n_atoms, n_frames, 1), np.float32)
@@ -660,11 +660,11 @@ def transformation_side_measurement(engine, n_atoms: int, n_frames: int) -> dict
     avg, launches = timed(lambda: engine.kinaci_heat_current(wrapped, vel, force, pe, 0.002),
                           "flux")
     result["kinaci_heat_current"] = entry(
-        "kinaci_kernel<float, false> + kinaci_offsets_kernel + kinaci_kernel<float, true>", avg,
-        launches, 10 * cell, "position 3 + velocity 3 + force 3 + potential energy 1; the two "
-                             "passes fetch 16 words for these 10",
-        kernels_on_record=["kinaci_kernel<float, false>", "kinaci_offsets_kernel",
-                           "kinaci_kernel<float, true>"])
+        "kinaci_stream_kernel + kinaci_offsets_kernel + sliced_weighted_sum_kernel", avg,
+        launches, 10 * cell, "position 3 + velocity 3 + force 3 + potential energy 1; the "
+                             "positions are read a second time (13 words fetched)",
+        kernels_on_record=["kinaci_stream_kernel", "kinaci_offsets_kernel",
+                           "sliced_weighted_sum_kernel"])
     for arr in (wrapped, vel, force, pe):
         arr.free()
     return result

@@ -400,6 +400,161 @@ __global__ __launch_bounds__(kThreads) void kinaci_kernel(
   }
 }
 
+// The same for float32 arrays with an even number of frames, as a stream in the manner of
+// flux_stream_kernel: wave = 128 consecutive frames (a slice), walking down the chunk's
+// atoms; position, velocity and force pass through the wave's LDS image, lane l then owns
+// the frames 2l, 2l+1.  The integral is split at the slice's start,
+//   I_a(t) = carry_a + dt * (sum of the power before the slice) + dt * (sum within it),
+// so that one pass over all four arrays needs nothing from other slices: it adds
+// pos * (carry + dt * within + pe) and leaves the slice's power sum per atom in `totals`;
+// the part pos * dt * before follows as a column sum of the positions alone, weighted per
+// slice and atom (sliced_weighted_sum_kernel), once kinaci_offsets_kernel has turned the
+// sums into the sums before each slice.  13 words per atom and frame are fetched for the
+// 10 that are needed (the two-launch scan above fetches 16).
+__global__ __launch_bounds__(kThreads) void kinaci_stream_kernel(
+    const float *__restrict__ pos, const float *__restrict__ vel,
+    const float *__restrict__ force, const float *__restrict__ pe, int64_t n_atoms,
+    int64_t n_frames, int64_t atoms_per_chunk, double dt, const double *__restrict__ carry,
+    double *__restrict__ totals, double *__restrict__ partial) {
+  constexpr int kWaves = kThreads / 64;
+  constexpr int kWords = kWaveFrames * 3;
+  __shared__ __align__(16) float image[kWaves][3 * kWords];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t slice = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  const int64_t t0 = slice * kWaveFrames;
+  if (t0 >= n_frames) return;  // no block-wide synchronisation below
+  const int frames_here = static_cast<int>(min<int64_t>(kWaveFrames, n_frames - t0));  // even
+  const int three_units = frames_here * 3 / 2;  // 8-byte units of a vector slice
+  const int pair_units = frames_here / 2;       // 8-byte units of the energy slice
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  float *my_pos = image[wave];
+  float *my_vel = image[wave] + kWords;
+  float *my_force = image[wave] + 2 * kWords;
+
+  f2v x_next[3], v_next[3], f_next[3], p_next;
+  // units past the slice's end re-read its last unit and become zero where they are used
+  auto fetch = [&](int64_t a) {
+    const int64_t at = a * n_frames + t0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int u = min(lane + 64 * j, three_units - 1);
+      x_next[j] = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(pos + at * 3) + u);
+      v_next[j] = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(vel + at * 3) + u);
+      f_next[j] = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(force + at * 3) + u);
+    }
+    p_next = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(pe + at) +
+                                        min(lane, pair_units - 1));
+  };
+
+  double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  if (a0 < a1) fetch(a0);
+  for (int64_t a = a0; a < a1; ++a) {
+    const f2v zero2 = f2v{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int u = lane + 64 * j;
+      const bool live = u < three_units;
+      *reinterpret_cast<f2v *>(my_pos + 2 * u) = live ? x_next[j] : zero2;
+      *reinterpret_cast<f2v *>(my_vel + 2 * u) = live ? v_next[j] : zero2;
+      *reinterpret_cast<f2v *>(my_force + 2 * u) = live ? f_next[j] : zero2;
+    }
+    const f2v p_cur = lane < pair_units ? p_next : zero2;
+    const double carry_a = carry[a];
+    if (a + 1 < a1) fetch(a + 1);
+    // the wave's own writes are visible to its later reads; keep the compiler from moving
+    // the reads of other lanes' words above them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float xw[6], vw[6], fw[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f2v tx = *reinterpret_cast<const f2v *>(my_pos + 6 * lane + 2 * j);
+      const f2v tv = *reinterpret_cast<const f2v *>(my_vel + 6 * lane + 2 * j);
+      const f2v tf = *reinterpret_cast<const f2v *>(my_force + 6 * lane + 2 * j);
+      xw[2 * j] = tx.x; xw[2 * j + 1] = tx.y;
+      vw[2 * j] = tv.x; vw[2 * j + 1] = tv.y;
+      fw[2 * j] = tf.x; fw[2 * j + 1] = tf.y;
+    }
+    // reads done before the next atom's image overwrites them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double power[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      double sum = static_cast<double>(fw[3 * f]) * static_cast<double>(vw[3 * f]);
+      sum = sum + static_cast<double>(fw[3 * f + 1]) * static_cast<double>(vw[3 * f + 1]);
+      sum = sum + static_cast<double>(fw[3 * f + 2]) * static_cast<double>(vw[3 * f + 2]);
+      power[f] = sum;  // zero for frames past the end: their words are zero
+    }
+    const double own = power[0] + power[1];
+    double incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double below = __shfl_up(incl, off);
+      if (lane >= off) incl = incl + below;
+    }
+    if (lane == 63) totals[slice * n_atoms + a] = incl;
+    const double before_lane = incl - own;
+    const double within[2] = {before_lane + power[0], before_lane + own};
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const double integral = carry_a + within[f] * dt;
+      const double e = integral + static_cast<double>(f == 0 ? p_cur.x : p_cur.y);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[f][i] = acc[f][i] + static_cast<double>(xw[3 * f + i]) * e;
+    }
+  }
+  if (lane >= pair_units) return;
+  double *dst = partial + static_cast<int64_t>(blockIdx.y) * n_frames * 3 + (t0 + 2 * lane) * 3;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dst[3 * f + i] = acc[f][i];
+}
+
+// partial[chunk][col] = scalar * sum over the chunk's atoms of w[col / cols_per_slice][a] *
+// x[a][col]: the column sum of weighted_sum_kernel with a weight per (slice of columns,
+// atom).  cols_per_slice is a multiple of four, so a thread's columns share their weight.
+__global__ __launch_bounds__(kThreads) void sliced_weighted_sum_kernel(
+    const float *__restrict__ x, const double *__restrict__ weights, double scalar,
+    int64_t n_atoms, int64_t row_len, int64_t cols_per_slice, int64_t atoms_per_chunk,
+    double *__restrict__ partial) {
+  const int64_t col = (static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x) * 4;
+  if (col >= row_len) return;
+  const int64_t a0 = static_cast<int64_t>(blockIdx.y) * atoms_per_chunk;
+  const int64_t a1 = min(n_atoms, a0 + atoms_per_chunk);
+  const double *w = weights + (col / cols_per_slice) * n_atoms;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const float *p = x + a0 * row_len + col;
+  int64_t a = a0;
+  for (; a + kUnroll <= a1; a += kUnroll) {
+    double vals[kUnroll][4];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) VecLoad<float, 4>::load(p + u * row_len, vals[u]);
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const double wa = w[a + u] * scalar;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[v] = acc[v] + wa * vals[u][v];
+    }
+    p += kUnroll * row_len;
+  }
+  for (; a < a1; ++a) {
+    double vals[4];
+    VecLoad<float, 4>::load(p, vals);
+    const double wa = w[a] * scalar;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] = acc[v] + wa * vals[v];
+    p += row_len;
+  }
+  double *dst = partial + static_cast<int64_t>(blockIdx.y) * row_len + col;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) dst[v] = acc[v];
+}
+
 // Per atom: totals[b][a] becomes the sum of the blocks before b; carry[a] moves on to
 // the integral at the batch's last frame (carry_next), the old value staying in `carry`
 // for the second launch.
@@ -790,13 +945,52 @@ int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
   MDX_TRY(to_device(vel, location, unit * 3, st_v, stream, &dv));
   MDX_TRY(to_device(force, location, unit * 3, st_f, stream, &df));
   MDX_TRY(to_device(pe, location, unit, st_p, stream, &dp));
-  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
   const size_t carry_bytes = sizeof(double) * static_cast<size_t>(n_atoms);
-  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
-  MDX_TRY(totals.alloc(carry_bytes * static_cast<size_t>(plan.col_blocks)));
   MDX_TRY(d_carry.alloc(carry_bytes));
   MDX_TRY(d_next.alloc(carry_bytes));
   MDX_HIP(hipMemcpyAsync(d_carry.ptr, carry, carry_bytes, hipMemcpyHostToDevice, stream));
+  // float32, even frame count, aligned arrays: the streaming form (MDX_KINACI_SCAN=1 keeps
+  // the two-launch scan, for comparison)
+  const char *scan_env = getenv("MDX_KINACI_SCAN");
+  if (stream_layout_ok(dtype, n_frames, {dx, dv, df, dp}) && (n_frames * 3) % 4 == 0 &&
+      !(scan_env != nullptr && scan_env[0] == '1')) {
+    const int64_t n_slices = ceil_div(n_frames, static_cast<int64_t>(kWaveFrames));
+    const ChunkPlan plan_a = plan_stream_chunks(n_atoms, n_frames);
+    const ChunkPlan plan_b = plan_chunks(n_atoms, n_cols / 4);
+    const int chunks = static_cast<int>(plan_a.n_chunks + plan_b.n_chunks);
+    MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(chunks) * n_cols));
+    MDX_TRY(totals.alloc(carry_bytes * static_cast<size_t>(n_slices)));
+    {
+      KernelTimer timer(MDX_SLOT_FLUX, stream);
+      hipLaunchKernelGGL(kinaci_stream_kernel,
+                         dim3(static_cast<unsigned>(plan_a.col_blocks),
+                              static_cast<unsigned>(plan_a.n_chunks)),
+                         dim3(kThreads), 0, stream, static_cast<const float *>(dx),
+                         static_cast<const float *>(dv), static_cast<const float *>(df),
+                         static_cast<const float *>(dp), n_atoms, n_frames,
+                         plan_a.atoms_per_chunk, dt, d_carry.as<double>(), totals.as<double>(),
+                         partial.as<double>());
+      hipLaunchKernelGGL(kinaci_offsets_kernel,
+                         dim3(static_cast<unsigned>(ceil_div(n_atoms, kThreads))),
+                         dim3(kThreads), 0, stream, totals.as<double>(), n_slices, n_atoms, dt,
+                         d_carry.as<double>(), d_next.as<double>());
+      hipLaunchKernelGGL(sliced_weighted_sum_kernel,
+                         dim3(static_cast<unsigned>(plan_b.col_blocks),
+                              static_cast<unsigned>(plan_b.n_chunks)),
+                         dim3(kThreads), 0, stream, static_cast<const float *>(dx),
+                         totals.as<double>(), dt, n_atoms, n_cols,
+                         static_cast<int64_t>(kWaveFrames) * 3, plan_b.atoms_per_chunk,
+                         partial.as<double>() + plan_a.n_chunks * n_cols);
+    }
+    MDX_HIP(hipGetLastError());
+    MDX_TRY(finish(partial, chunks, 1, n_cols, out, out_location, accumulate, stream));
+    MDX_HIP(hipMemcpyAsync(carry, d_next.ptr, carry_bytes, hipMemcpyDeviceToHost, stream));
+    MDX_HIP(hipStreamSynchronize(stream));
+    return MDX_OK;
+  }
+  const ChunkPlan plan = plan_chunks(n_atoms, n_frames);
+  MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
+  MDX_TRY(totals.alloc(carry_bytes * static_cast<size_t>(plan.col_blocks)));
   dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
   const unsigned atom_blocks = static_cast<unsigned>(ceil_div(n_atoms, kThreads));
 #define MDX_KINACI(TYPE)                                                                      \

@@ -353,10 +353,14 @@ def test_msd_three_components_small_lags_far_from_origin(gpu, dtype, offset, D):
 # ------------------------------------------------- Kinaci integrated heat current
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("n_atoms,n_frames", [(1, 1), (5, 7), (33, 1000), (130, 257), (7, 2049)])
+@pytest.mark.parametrize("n_atoms,n_frames", [(1, 1), (5, 7), (33, 1000), (130, 257), (7, 2049),
+                                              (5, 4), (33, 132), (130, 256), (70, 2052),
+                                              (300, 128)])
 def test_kinaci_heat_current_matches_oracle(gpu, dtype, n_atoms, n_frames):
-    """Running integral of force.velocity per atom (scanned over blocks of 256 frames on
-    the GPU) in front of the atom reduction; sizes around the block and chunk edges."""
+    """Running integral of force.velocity per atom in front of the atom reduction: float32
+    arrays whose frame count is a multiple of four take the streaming form (slices of 128
+    frames, the integral split at the slice's start), everything else the scan over blocks
+    of 256 frames; sizes around the slice, block and chunk edges."""
     rng = np.random.default_rng(31)
     pos = np.cumsum(rng.normal(size=(n_atoms, n_frames, 3)), axis=1).astype(dtype)
     vel = rng.normal(size=(n_atoms, n_frames, 3)).astype(dtype)
@@ -366,6 +370,25 @@ def test_kinaci_heat_current_matches_oracle(gpu, dtype, n_atoms, n_frames):
     ref, ref_carry = orc.kinaci_heat_current(pos, vel, force, pe, 0.002, 5)
     assert_close(got, ref, rtol=1e-12)
     assert_close(carry, ref_carry, rtol=1e-12)
+
+
+def test_kinaci_heat_current_stream_and_scan_agree(gpu, monkeypatch):
+    rng = np.random.default_rng(33)
+    n_atoms, n_frames = 257, 1300
+    pos = np.cumsum(rng.normal(size=(n_atoms, n_frames, 3)), axis=1).astype(np.float32)
+    vel = rng.normal(size=(n_atoms, n_frames, 3)).astype(np.float32)
+    force = rng.normal(size=(n_atoms, n_frames, 3)).astype(np.float32)
+    pe = -rng.random((n_atoms, n_frames, 1)).astype(np.float32)
+    start = rng.normal(size=n_atoms)
+    streamed, carry_s = gpu.kinaci_heat_current(pos, vel, force, pe, dt=0.01, carry=start)
+    monkeypatch.setenv("MDX_KINACI_SCAN", "1")
+    scanned, carry_b = gpu.kinaci_heat_current(pos, vel, force, pe, dt=0.01, carry=start)
+    assert_close(streamed, scanned, rtol=1e-13)
+    assert_close(carry_s, carry_b, rtol=1e-13)
+    ref, ref_carry = orc.kinaci_heat_current(pos, vel, force, pe, 0.01, 1,
+                                             carry=start)
+    assert_close(streamed, ref, rtol=1e-12)
+    assert_close(carry_s, ref_carry, rtol=1e-12)
 
 
 def test_kinaci_heat_current_carries_the_integral_across_batches(gpu):
