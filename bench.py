@@ -389,6 +389,7 @@ def main() -> None:
             result["flux_reductions"] = flux_side_measurement(engine, args.flux_atoms, 100000)
             result["transformations"] = transformation_side_measurement(
                 engine, args.flux_atoms, 100000)
+            result["adf"] = adf_side_measurement(engine)
         if not args.skip_host_input:
             result["host_input"] = host_input_measurement(engine, min(fps, 1024))
         if args.api_frames > 0:
@@ -668,6 +669,36 @@ def transformation_side_measurement(engine, n_atoms: int, n_frames: int) -> dict
     for arr in (wrapped, vel, force, pe):
         arr.free()
     return result
+
+
+def adf_side_measurement(engine) -> dict:
+    """AngularDistributionFunction's batch body (neighbour search within the cutoff, all
+    triples of every atom's neighbourhood, weighted angle histograms) on the 10k-atom melt:
+    not part of the metric, reported so that the kernel has a number next to the others."""
+    n_frames = 16
+    species = []
+    for s_idx, n in enumerate((N_NA, N_CL)):
+        arr = engine.DeviceArray((n, n_frames, 3), np.float32)
+        arr.fill_uniform(seed=60 + s_idx, lo=0.0, hi=BOX)
+        species.append(arr)
+    edges = np.histogram_bin_edges(np.zeros(1, np.float32), bins=500, range=(0.0, 3.15))
+    out = {"workload": f"{N_NA} + {N_CL} atoms uniform in a box of {BOX}, {n_frames} frames per "
+                       "call, 500 angle bins, device resident"}
+    for cutoff in (6.0, 10.0):
+        engine.adf_accumulate(species, [BOX] * 3, cutoff, edges)
+        engine.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            _, triples = engine.adf_accumulate(species, [BOX] * 3, cutoff, edges)
+        engine.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[f"cutoff_{cutoff:g}"] = {"frames_per_s": n_frames / dt, "ms_per_call": dt * 1e3,
+                                     "triples_per_frame": float(triples.sum()) / n_frames,
+                                     "triples_per_s": float(triples.sum()) / dt}
+    for arr in species:
+        arr.free()
+    return out
 
 
 def api_measurement(n_frames: int) -> dict:
