@@ -558,13 +558,27 @@ __global__ __launch_bounds__(kThreads) void sliced_weighted_sum_kernel(
 // Per atom: totals[b][a] becomes the sum of the blocks before b; carry[a] moves on to
 // the integral at the batch's last frame (carry_next), the old value staying in `carry`
 // for the second launch.
-__global__ __launch_bounds__(kThreads) void kinaci_offsets_kernel(
+// Blocks of one wave: a thread per atom leaves few waves, so they are spread over the chip.
+__global__ __launch_bounds__(64) void kinaci_offsets_kernel(
     double *__restrict__ totals, int64_t n_blocks, int64_t n_atoms, double dt,
     const double *__restrict__ carry, double *__restrict__ carry_next) {
-  const int64_t a = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t a = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (a >= n_atoms) return;
   double run = 0.0;
-  for (int64_t b = 0; b < n_blocks; ++b) {
+  int64_t b = 0;
+  // eight loads in flight: the entries of an atom lie n_atoms apart and each is read
+  // before it is overwritten
+  for (; b + 8 <= n_blocks; b += 8) {
+    double own[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) own[u] = totals[(b + u) * n_atoms + a];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      totals[(b + u) * n_atoms + a] = run;
+      run = run + own[u];
+    }
+  }
+  for (; b < n_blocks; ++b) {
     const double own = totals[b * n_atoms + a];
     totals[b * n_atoms + a] = run;
     run = run + own;
@@ -971,8 +985,8 @@ int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
                          plan_a.atoms_per_chunk, dt, d_carry.as<double>(), totals.as<double>(),
                          partial.as<double>());
       hipLaunchKernelGGL(kinaci_offsets_kernel,
-                         dim3(static_cast<unsigned>(ceil_div(n_atoms, kThreads))),
-                         dim3(kThreads), 0, stream, totals.as<double>(), n_slices, n_atoms, dt,
+                         dim3(static_cast<unsigned>(ceil_div(n_atoms, 64))),
+                         dim3(64), 0, stream, totals.as<double>(), n_slices, n_atoms, dt,
                          d_carry.as<double>(), d_next.as<double>());
       hipLaunchKernelGGL(sliced_weighted_sum_kernel,
                          dim3(static_cast<unsigned>(plan_b.col_blocks),
@@ -992,7 +1006,7 @@ int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
   MDX_TRY(partial.alloc(sizeof(double) * static_cast<size_t>(plan.n_chunks) * n_cols));
   MDX_TRY(totals.alloc(carry_bytes * static_cast<size_t>(plan.col_blocks)));
   dim3 grid(static_cast<unsigned>(plan.col_blocks), static_cast<unsigned>(plan.n_chunks));
-  const unsigned atom_blocks = static_cast<unsigned>(ceil_div(n_atoms, kThreads));
+  const unsigned atom_blocks = static_cast<unsigned>(ceil_div(n_atoms, 64));
 #define MDX_KINACI(TYPE)                                                                      \
   do {                                                                                        \
     hipLaunchKernelGGL((kinaci_kernel<TYPE, false>), grid, dim3(kThreads), 0, stream,         \
@@ -1000,7 +1014,7 @@ int mdx_kinaci_heat_current(const void *pos, const void *vel, const void *force,
                        static_cast<const TYPE *>(df), static_cast<const TYPE *>(dp), n_atoms, \
                        n_frames, plan.atoms_per_chunk, dt, d_carry.as<double>(),              \
                        totals.as<double>(), partial.as<double>());                            \
-    hipLaunchKernelGGL(kinaci_offsets_kernel, dim3(atom_blocks), dim3(kThreads), 0, stream,   \
+    hipLaunchKernelGGL(kinaci_offsets_kernel, dim3(atom_blocks), dim3(64), 0, stream,         \
                        totals.as<double>(), plan.col_blocks, n_atoms, dt,                     \
                        d_carry.as<double>(), d_next.as<double>());                            \
     hipLaunchKernelGGL((kinaci_kernel<TYPE, true>), grid, dim3(kThreads), 0, stream,          \
