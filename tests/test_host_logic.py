@@ -433,3 +433,24 @@ def test_hdf5_reader_says_what_is_missing(tmp_path, monkeypatch):
     monkeypatch.setitem(sys.modules, "h5py", None)  # import h5py -> ImportError
     with pytest.raises(ImportError, match="h5py"):
         sdb.open_database(path).check_existence("Na/Positions")
+
+
+def test_calculators_are_imported_on_first_use():
+    """The calculators package resolves a name to its module when it is asked for: every
+    advertised name resolves, an unknown one raises AttributeError, and the pair
+    histogram's calculator comes without the SciPy parts of the correlation calculators."""
+    import subprocess
+    import sys
+
+    from lammps_analysis_amd import calculators
+
+    for name in calculators.__all__:
+        assert getattr(calculators, name).__name__ == name
+    with pytest.raises(AttributeError):
+        calculators.NoSuchCalculator
+    code = ("import sys; from lammps_analysis_amd.calculators import "
+            "RadialDistributionFunction; print(any(m == 'scipy' or m.startswith('scipy.') "
+            "for m in sys.modules))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         cwd=str(pathlib.Path(__file__).resolve().parents[1]), check=True)
+    assert out.stdout.strip() == "False"
