@@ -768,6 +768,8 @@ def api_measurement(n_frames: int) -> dict:
         gk_again_s = time.perf_counter() - t0
         keys = sorted(rdf["melt"].data_dict)
     finally:
+        from lammps_analysis_amd.database.simulation_database import release_read_maps
+        release_read_maps()  # the store's files are only freed once nothing maps them
         shutil.rmtree(workdir, ignore_errors=True)
     rdf_frames = n_frames - 1   # number_of_configurations=-1 samples n - 1 frames
     return {

@@ -12,10 +12,10 @@ from abc import ABC
 from dataclasses import dataclass
 
 import numpy as np
-from scipy.integrate import cumulative_trapezoid
 
 from .. import engine, parallel
 from ..database.mdsuite_properties import mdsuite_properties
+from ..utils.calculator_helper_methods import cumulative_trapezoid
 from ..utils.config import config
 from ..utils.constants import DatasetKeys
 from ..utils.units import boltzmann_constant, elementary_charge

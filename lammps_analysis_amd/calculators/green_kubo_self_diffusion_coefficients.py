@@ -12,10 +12,10 @@ from dataclasses import dataclass
 from typing import Any, List, Union
 
 import numpy as np
-from scipy.integrate import cumulative_trapezoid
 
 from .. import engine, parallel
 from ..database.mdsuite_properties import mdsuite_properties
+from ..utils.calculator_helper_methods import cumulative_trapezoid
 from ..utils.config import config
 from .calculator import call
 from .trajectory_calculator import TrajectoryCalculator

@@ -17,10 +17,13 @@ intermediate copy.
 """
 from __future__ import annotations
 
+import collections
 import dataclasses
 import json
 import logging
+import os
 import pathlib
+import threading
 import typing
 from typing import List
 
@@ -44,6 +47,39 @@ def _writer_only(method):
     return wrapper
 
 STORAGE_DTYPE = np.float32  # the reference's h5py datasets default to float32 (:491-497)
+
+# Read-only memory maps stay open between loads.  Setting up and tearing down the page
+# tables of a multi-gigabyte mapping costs tens of milliseconds per calculator call, and
+# pages touched once need no fault the second time.  A shared mapping shows whatever is
+# written to the file through any other mapping; it goes stale only when the file is
+# replaced or resized, so the key holds the inode and the size.
+_READ_MAPS: "collections.OrderedDict[tuple, np.memmap]" = collections.OrderedDict()
+_READ_MAPS_LIMIT = 32
+_READ_MAPS_LOCK = threading.Lock()
+
+
+def _read_map(path: pathlib.Path) -> np.memmap:
+    stat = os.stat(path)
+    key = (str(path), stat.st_ino, stat.st_size)
+    with _READ_MAPS_LOCK:
+        mapped = _READ_MAPS.get(key)
+        if mapped is not None:
+            _READ_MAPS.move_to_end(key)
+            return mapped
+        for stale in [k for k in _READ_MAPS if k[0] == key[0]]:
+            del _READ_MAPS[stale]
+        mapped = np.load(path, mmap_mode="r")
+        _READ_MAPS[key] = mapped
+        while len(_READ_MAPS) > _READ_MAPS_LIMIT:
+            _READ_MAPS.popitem(last=False)
+        return mapped
+
+
+def release_read_maps() -> None:
+    """Forget the cached read-only mappings (a deleted store's files stay allocated as long
+    as a mapping of them is alive)."""
+    with _READ_MAPS_LOCK:
+        _READ_MAPS.clear()
 
 
 @dataclasses.dataclass(frozen=True)
@@ -263,7 +299,7 @@ class Database:
                 my_slice = select_slice[name.split("/")[0]]
             else:
                 my_slice = select_slice
-            mm = np.load(self._file(name), mmap_mode="r")
+            mm = _read_map(self._file(name))
             if (isinstance(my_slice, tuple) and len(my_slice) >= 2
                     and all(isinstance(part, (list, np.ndarray)) for part in my_slice[:2])):
                 # an atom list and a frame list select a block (every listed atom at every

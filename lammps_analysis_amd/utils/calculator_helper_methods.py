@@ -8,12 +8,19 @@ file (:110-184) belong to the distinct-diffusion calculators.
 from __future__ import annotations
 
 import numpy as np
-from scipy.interpolate import UnivariateSpline
-from scipy.optimize import curve_fit
 
 
 def _line(x, m, a):
     return m * x + a
+
+
+def cumulative_trapezoid(y: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """``scipy.integrate.cumulative_trapezoid(y, x=x)`` for one-dimensional series, in
+    SciPy's own operation order (``cumsum(diff(x) * (y[1:] + y[:-1]) / 2.0)``), so that the
+    Green-Kubo calculators need no SciPy import for a running integral."""
+    y = np.asarray(y, dtype=float)
+    x = np.asarray(x, dtype=float)
+    return np.cumsum(np.diff(x) * (y[1:] + y[:-1]) / 2.0)
 
 
 def fit_einstein_curve(x_data: np.ndarray, y_data: np.ndarray, fit_max_index: int):
@@ -24,6 +31,11 @@ def fit_einstein_curve(x_data: np.ndarray, y_data: np.ndarray, fit_max_index: in
     fitted to ``[start, i)`` for every ``i`` from ``start + 2`` on.  Returns the
     fit at ``i == fit_max_index`` plus all slopes and their standard errors.
     """
+    # SciPy's interpolation and optimisation packages take a few tenths of a second to
+    # import; only the fits need them
+    from scipy.interpolate import UnivariateSpline
+    from scipy.optimize import curve_fit
+
     x_data = np.asarray(x_data, dtype=float)
     y_data = np.asarray(y_data, dtype=float)
     second = UnivariateSpline(x_data, y_data, s=0, k=4).derivative(n=2)(x_data)
