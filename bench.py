@@ -62,10 +62,13 @@ NBINS = int(CUTOFF / 0.01)
 # scratch/valu_probe_f32.hip (profiles/r02_valu_probe.txt; 1024 SIMDs, counted at 2.4 GHz),
 # and the instructions of one loop iteration (4 pairs per lane) of the fast RDF kernel,
 # read off its ISA: 6 packed subtractions, 24 folds, 2 packed multiplies and 6 packed fma,
-# 4 square roots, 8 compares, 4 shifts and 8 masks.
-VALU_CYCLES = {"packed": 4.6, "sub_abs": 2.75, "sqrt": 8.4, "compare": 5.1, "shift": 2.3,
-               "mask": 2.4}
-FAST_LOOP_MIX = {"packed": 14, "sub_abs": 24, "sqrt": 4, "compare": 8, "shift": 4, "mask": 8}
+# 4 square roots, 4 unsigned minima (pairs beyond the cutoff go to a dump word), 4 compares
+# (near a bin edge), 4 shifts and 8 masks.  The probe prices every instruction alone, so the
+# sum is a model of the loop's issue time, not a strict lower bound.
+VALU_CYCLES = {"packed": 4.6, "sub_abs": 2.75, "sqrt": 8.4, "compare": 5.1, "min": 4.5,
+               "shift": 2.3, "mask": 2.4}
+FAST_LOOP_MIX = {"packed": 14, "sub_abs": 24, "sqrt": 4, "compare": 4, "min": 4, "shift": 4,
+                 "mask": 8}
 PAIRS_PER_LOOP_ITERATION = 4
 
 

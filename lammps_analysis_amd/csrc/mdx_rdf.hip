@@ -68,6 +68,9 @@ using namespace mdx;
 namespace {
 
 constexpr int kTile = 256;          // atoms per tile == threads per block
+// Words behind the fast kernel's LDS histogram that take the pairs beyond the cutoff, one
+// per lane of a wave, so that every pair is counted somewhere and none needs a branch.
+constexpr int kDumpWords = 64;
 constexpr int kMaxFramesPerGroup = 64;
 
 struct TilePair {
@@ -102,6 +105,7 @@ struct RdfParams {
   uint32_t fast_frac_mask;   // (1 << F) - 1
   uint32_t fast_edge_units;  // E: a fraction below E grid units means "near an edge"
   uint32_t fast_keep_bits;   // float bits below this: position < nbins + E grid units
+  uint32_t fast_dump_bits;   // bits of position nbins + 1 with every fraction bit set
   int fast_ok;               // 0: the bound is too wide for this geometry, do not use
   float cull_gap2;           // tile pairs with a squared box gap above this hold no pair in reach
 };
@@ -608,7 +612,8 @@ __device__ __forceinline__ void fast_j_range(
     uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
   const uint32_t shift = in_vgpr(p.fast_frac_bits - 2u);
   const uint32_t edge = p.fast_edge_units;
-  const uint32_t keep_bits = p.fast_keep_bits;
+  // position nbins + 1 + lane: 64 distinct words, so the lanes of a wave never collide there
+  const uint32_t dump = p.fast_dump_bits + (static_cast<uint32_t>(tid & 63) << p.fast_frac_bits);
   const v2f xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
   const v2f scale2 = {scale, scale}, magic2 = {magic, magic};
   float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
@@ -642,17 +647,17 @@ __device__ __forceinline__ void fast_j_range(
       bits[2 * h] = __float_as_uint(t2.x);
       bits[2 * h + 1] = __float_as_uint(t2.y);
     }
-    bool keep[4], near[4];
+    // A pair beyond the cutoff goes to the lane's dump word (every fraction bit set: never
+    // "near an edge"); a NaN (padding) compares above every position and goes there too.
+    bool near[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      keep[u] = bits[u] < keep_bits;  // a NaN (padding) compares above every position
-      if (kDiag) keep[u] = keep[u] && (j0 + u > tid);
-      near[u] = keep[u] && ((bits[u] & frac_mask) < edge);
+      bits[u] = min(bits[u], dump);
+      if (kDiag) bits[u] = (j0 + u > tid) ? bits[u] : dump;
+      near[u] = (bits[u] & frac_mask) < edge;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (keep[u]) lds_count((bits[u] >> shift) & addr_mask, one);
-    }
+    for (int u = 0; u < 4; ++u) lds_count((bits[u] >> shift) & addr_mask, one);
     if (__builtin_expect(near[0] || near[1] || near[2] || near[3], 0)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -722,7 +727,8 @@ __device__ __forceinline__ void fast_tile_loop_quarters(
 // (on a key change and at the end).  Every block claims chunks with one global atomic
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
 // pace.  Frames that are not "compact" are skipped (the table kernel takes them).
-// LDS layout: uint32 hist[lds_hist_words] | uint8 queue[kTile][kQueueSlots] | uint32 claim.
+// LDS layout: uint32 hist[lds_hist_words] (bins, the overflow bin, kDumpWords dump words) |
+// uint8 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
 // The loop needs every wave a SIMD can hold to hide its dependent chains (sub, sub, mul,
@@ -1085,8 +1091,9 @@ void rdf_fast_setup(RdfParams &p) {
     if (p.half_box[c] * 2.0f != p.box[c]) return;  // not exact (denormal box)
     if (p.t_far[c] <= 0.0f) return;                // no frame may use the wrapped form
   }
+  // the mantissa field holds the bins, the overflow bin and the 64 dump words behind it
   int k = 1;
-  while ((1 << k) < p.nbins + 3) ++k;
+  while ((1 << k) < p.nbins + 2 + kDumpWords) ++k;
   if (k > 15) return;
   const int frac_bits = 23 - k;
   const double u = 0x1p-24;
@@ -1105,6 +1112,8 @@ void rdf_fast_setup(RdfParams &p) {
   p.fast_magic = static_cast<float>(std::ldexp(1.0, k) + shift_units * grid);  // exact
   const float top = static_cast<float>(std::ldexp(1.0, k) + p.nbins);
   p.fast_keep_bits = float_bits(top) + p.fast_edge_units;
+  p.fast_dump_bits = float_bits(static_cast<float>(std::ldexp(1.0, k) + p.nbins + 1)) +
+                     p.fast_frac_mask;
   p.fast_ok = 1;
 }
 
@@ -1620,7 +1629,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   }
 
   if (!literal && p.fast_ok) {
-    h->fast_lds_hist_words = (nbins + 1 + 3) & ~3;
+    h->fast_lds_hist_words = (nbins + 1 + kDumpWords + 3) & ~3;
     h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
                         static_cast<size_t>(kTile) * kQueueSlots + 16;
     if (h->fast_lds_bytes <= 160 * 1024) {
