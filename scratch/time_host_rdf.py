@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, numpy as np
 import lammps_analysis_amd.engine as engine
 N, F = 5000, 1024
