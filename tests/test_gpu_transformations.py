@@ -93,6 +93,38 @@ def test_unwrap_stream_kernel_matches_oracle(gpu, monkeypatch, n_frames):
             np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
 
 
+def test_unwrap_stream_kernel_quiet_and_jumping_steps(gpu, monkeypatch):
+    """Slow walkers in a large box: most 256-frame steps see no move of 0.48 box lengths
+    and take the kernel's shortcut (input plus the current image shift, no scan), the
+    others hold a crossing; whole rows, three batches with the carry, and a start that is
+    already some boxes away."""
+    monkeypatch.setenv("MDX_UNWRAP_STREAM_MIN_ATOMS", "1")
+    rng = np.random.default_rng(77)
+    box = np.array([5.0, 6.0, 7.0])
+    n_atoms, n_frames = 9, 4096
+    wrapped, free = _walk(rng, n_atoms, n_frames, box, step=0.004)
+    wrapped = wrapped.astype(np.float32)
+    crossings = np.abs(np.diff(wrapped, axis=1)) > 0.4 * box
+    # both kinds of step must occur
+    steps_with = crossings[:, :4095 // 256 * 256].reshape(n_atoms, -1, 256, 3).any(axis=(2, 3))
+    assert steps_with.any() and not steps_with.all()
+    got, carry = gpu.unwrap_coordinates(wrapped, box, out_dtype=np.float32)
+    ref, ref_carry = ort.unwrap_coordinates(wrapped, box)
+    np.testing.assert_array_equal(got, ref.astype(np.float32))
+    np.testing.assert_array_equal(carry["last_pos"], ref_carry["last_pos"])
+    np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+    carry = {"last_pos": wrapped[:, 0].astype(np.float64),
+             "last_image_box": rng.integers(-3, 4, size=(n_atoms, 3)).astype(np.float64)}
+    ref_carry = {k: v.copy() for k, v in carry.items()}
+    for a, b in ((0, 1364), (1364, 2732), (2732, 4096)):
+        piece = np.ascontiguousarray(wrapped[:, a:b])
+        got, carry = gpu.unwrap_coordinates(piece, box, carry=carry, out_dtype=np.float32)
+        ref, ref_carry = ort.unwrap_coordinates(piece, box, carryover=ref_carry)
+        np.testing.assert_array_equal(got, ref.astype(np.float32))
+        np.testing.assert_array_equal(carry["last_pos"], ref_carry["last_pos"])
+        np.testing.assert_array_equal(carry["last_image_box"], ref_carry["last_image_box"])
+
+
 def test_unwrap_stream_kernel_exact_rounding_cases(gpu, monkeypatch):
     """Differences that are exact half-integer multiples of the box (ties round to even),
     jumps of many boxes, and frames that do not move: the quick rejection of small
