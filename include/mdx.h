@@ -251,6 +251,9 @@ int mdx_rdf_reduce(mdx_rdf_t handle, mdx_comm_t comm);
  * per-species charge of transformations.py:406-414) or a host array of n_atoms
  * float64 multiplied by scalar_weight.  accumulate != 0 adds to `out` (the
  * tf.add_n over species), else overwrites.  out is [n_frames][k] float64.
+ * With x and out both on the device and no weight array the call returns when the work is
+ * queued on the library's stream; every later library call is ordered behind it, and
+ * mdx_synchronize, or any call that returns data to the host, waits for it.
  */
 int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_atoms,
                           int64_t n_frames, int k, const double *weights,
@@ -366,7 +369,9 @@ int mdx_unwrap_coordinates(const void *pos, int dtype, int location, int64_t n_a
  *   MDX_MAP_VELOCITY        (x[t+1] - x[t]) / params[0], last frame = the one before
  *                           VelocityFromPositions (velocity_from_positions.py:42-58)
  * params = box lengths, or {dt, unused, unused} for the velocity.  aux has the
- * dtype and location of x and is read by MDX_MAP_UNWRAP_INDICES only.
+ * dtype and location of x and is read by MDX_MAP_UNWRAP_INDICES only.  With input and
+ * output on the device the call returns when the work is queued on the library's stream
+ * (see mdx_weighted_atom_sum).
  */
 #define MDX_MAP_WRAP 0
 #define MDX_MAP_WRAP_CENTERED 1

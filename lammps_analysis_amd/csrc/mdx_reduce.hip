@@ -789,7 +789,10 @@ int mdx_weighted_atom_sum(const void *x, int dtype, int x_location, int64_t n_at
   }
   MDX_TRY(finish(partial, static_cast<int>(plan.n_chunks), 1, row_len, out, out_location,
                  accumulate, stream));
-  // scoped device buffers are released on return
+  // Device to device: the work stays queued.  The scoped device buffers go back to the
+  // library's cache on return, and whoever takes them next queues on this same stream.
+  if (x_location == MDX_DEVICE && out_location == MDX_DEVICE && weights == nullptr)
+    return MDX_OK;
   MDX_HIP(hipStreamSynchronize(stream));
   return MDX_OK;
 }

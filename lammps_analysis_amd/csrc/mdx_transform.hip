@@ -699,6 +699,7 @@ int mdx_map_coordinates(int op, const void *x, const void *aux, int dtype, int l
 #undef MDX_LAUNCH_MAP
 #undef MDX_LAUNCH_MAP_T
   MDX_HIP(hipGetLastError());
+  if (location == MDX_DEVICE && out_location == MDX_DEVICE) return MDX_OK;  // stays queued
   if (out_location == MDX_HOST)
     MDX_HIP(hipMemcpyAsync(out, dout, n * dtype_size(out_dtype), hipMemcpyDeviceToHost, stream));
   MDX_HIP(hipStreamSynchronize(stream));
