@@ -65,6 +65,11 @@ int mdx_synchronize(void);
 int mdx_malloc(void **dptr, size_t bytes);
 int mdx_free(void *dptr);
 int mdx_memcpy_h2d(void *dptr, const void *host, size_t bytes);
+/* n_rows rows of row_bytes that lie pitch_bytes apart in host memory (a frame range of the
+ * store's [n_particles][n_configurations][n_dims] arrays, mdsuite/database/
+ * simulation_database.py:594-639 with a frame slice) arrive back to back at dptr. */
+int mdx_memcpy_h2d_rows(void *dptr, const void *host, int64_t n_rows, size_t row_bytes,
+                        size_t pitch_bytes);
 int mdx_memcpy_d2h(void *host, const void *dptr, size_t bytes);
 int mdx_memset(void *dptr, int byte_value, size_t bytes);
 /* The library keeps the scratch blocks its calls free in a per-device cache (at

@@ -73,6 +73,8 @@ SIGNATURES = {
     "mdx_malloc": (ctypes.c_int, [c_void_pp, ctypes.c_size_t]),
     "mdx_free": (ctypes.c_int, [ctypes.c_void_p]),
     "mdx_memcpy_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "mdx_memcpy_h2d_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_size_t, ctypes.c_size_t]),
     "mdx_memcpy_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     "mdx_memset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
     "mdx_release_cached_memory": (ctypes.c_int, []),

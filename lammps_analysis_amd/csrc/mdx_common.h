@@ -110,6 +110,9 @@ int to_device(const void *src, int location, size_t bytes, DeviceBuffer &staging
 // Host-to-device copy in stream order; large ranges are pipelined through page-locked
 // memory.  The host range has been read when the call returns.
 int upload(void *dst, const void *src, size_t bytes, hipStream_t stream);
+// The same for n_rows rows of row_bytes lying `pitch` bytes apart on the host.
+int upload_rows(void *dst, const void *src, int64_t n_rows, size_t row_bytes, size_t pitch,
+                hipStream_t stream);
 
 // Brackets the kernel launches issued during its lifetime with HIP events when
 // profiling is enabled (mdx_profile_enable); free otherwise.

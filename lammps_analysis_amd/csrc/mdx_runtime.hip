@@ -233,6 +233,65 @@ int upload(void *dst, const void *src, size_t bytes, hipStream_t stream) {
   return MDX_OK;
 }
 
+// The same for rows that lie `pitch` bytes apart in host memory (a frame range of an
+// [atoms][frames][k] array): dst receives them back to back.  Whole rows are gathered into
+// the page-locked twins by the copy threads, so the strided source is read once and no
+// contiguous host copy is made first.
+int upload_rows(void *dst, const void *src, int64_t n_rows, size_t row_bytes, size_t pitch,
+                hipStream_t stream) {
+  if (n_rows <= 0 || row_bytes == 0) return MDX_OK;
+  if (pitch == row_bytes) return upload(dst, src, static_cast<size_t>(n_rows) * row_bytes, stream);
+  int dev = 0;
+  MDX_HIP(hipGetDevice(&dev));
+  const char *from = static_cast<const char *>(src);
+  char *to = static_cast<char *>(dst);
+  if (row_bytes <= kUploadChunk && dev >= 0 && dev < kMaxDevices) {
+    std::lock_guard<std::mutex> lock(g_upload_mutex);
+    if (prepare_upload_twins_locked(dev)) {
+      UploadTwins &tw = g_upload[dev];
+      const int64_t rows_per_chunk = std::max<int64_t>(1, static_cast<int64_t>(kUploadChunk / row_bytes));
+      int index = 0;
+      for (int64_t r0 = 0; r0 < n_rows; r0 += rows_per_chunk, ++index) {
+        const int b = index & 1;
+        const int64_t rows = std::min(rows_per_chunk, n_rows - r0);
+        if (index >= 2) MDX_HIP(hipEventSynchronize(tw.sent[b]));  // the twin has left
+        char *twin = static_cast<char *>(tw.pinned[b]);
+        auto part = [=](int64_t a0, int64_t a1) {
+          for (int64_t r = a0; r < a1; ++r)
+            memcpy(twin + static_cast<size_t>(r) * row_bytes,
+                   from + static_cast<size_t>(r0 + r) * pitch, row_bytes);
+        };
+        const int64_t share = (rows + kUploadThreads - 1) / kUploadThreads;
+        std::thread workers[kUploadThreads - 1];
+        int started = 0;
+        if (static_cast<size_t>(rows) * row_bytes >= (size_t(1) << 20)) {
+          for (int t = 1; t < kUploadThreads; ++t) {
+            const int64_t a0 = std::min<int64_t>(rows, share * t);
+            const int64_t a1 = std::min<int64_t>(rows, share * (t + 1));
+            if (a1 > a0) workers[started++] = std::thread(part, a0, a1);
+          }
+          part(0, std::min<int64_t>(rows, share));
+        } else {
+          part(0, rows);
+        }
+        for (int t = 0; t < started; ++t) workers[t].join();
+        MDX_HIP(hipMemcpyAsync(to + static_cast<size_t>(r0) * row_bytes, twin,
+                               static_cast<size_t>(rows) * row_bytes, hipMemcpyHostToDevice,
+                               stream));
+        MDX_HIP(hipEventRecord(tw.sent[b], stream));
+      }
+      MDX_HIP(hipEventSynchronize(tw.sent[0]));
+      if (index >= 2) MDX_HIP(hipEventSynchronize(tw.sent[1]));
+      return MDX_OK;
+    }
+  }
+  // rows longer than a twin, or no page-locked memory to be had: the driver's pitched copy
+  MDX_HIP(hipMemcpy2DAsync(dst, row_bytes, src, pitch, row_bytes, static_cast<size_t>(n_rows),
+                           hipMemcpyHostToDevice, stream));
+  MDX_HIP(hipStreamSynchronize(stream));
+  return MDX_OK;
+}
+
 void release_upload_twins() {
   std::lock_guard<std::mutex> lock(g_upload_mutex);
   int current = 0;
@@ -412,6 +471,17 @@ int mdx_memcpy_h2d(void *dptr, const void *host, size_t bytes) {
   hipStream_t s;
   MDX_TRY(get_stream(&s));
   MDX_TRY(upload(dptr, host, bytes, s));
+  MDX_HIP(hipStreamSynchronize(s));
+  return MDX_OK;
+}
+
+int mdx_memcpy_h2d_rows(void *dptr, const void *host, int64_t n_rows, size_t row_bytes,
+                        size_t pitch_bytes) {
+  MDX_REQUIRE(dptr != nullptr && host != nullptr, "null pointer");
+  MDX_REQUIRE(n_rows >= 0 && pitch_bytes >= row_bytes, "rows must not overlap");
+  hipStream_t s;
+  MDX_TRY(get_stream(&s));
+  MDX_TRY(upload_rows(dptr, host, n_rows, row_bytes, pitch_bytes, s));
   MDX_HIP(hipStreamSynchronize(s));
   return MDX_OK;
 }

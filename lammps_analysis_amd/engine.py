@@ -140,15 +140,37 @@ def uniform_fill_at(index: np.ndarray, seed: int, lo: float, hi: float) -> np.nd
     return (lo32 + (span * u).astype(np.float32)).astype(np.float32)
 
 
-def _as_input(x: ArrayLike):
-    """(pointer, dtype code, location, shape, keepalive) of an input array."""
+def _as_input(x: ArrayLike, rows: bool = False):
+    """(pointer, dtype code, location, shape, keepalive) of an input array.  ``rows``: a
+    frame range of a larger host array may be uploaded here, row by row (entry points with a
+    single array argument)."""
     if isinstance(x, DeviceArray):
         return x.ptr, _dtype_code(x.dtype), MDX_DEVICE, x.shape, x
     arr = np.asarray(x)
     if arr.dtype not in (np.float32, np.float64):
         arr = arr.astype(np.float64)
+    if rows and _is_frame_range(arr):
+        # a frame range of a stored [atoms][frames][k] array (what the batch loader hands
+        # over): its rows go to the device as they lie, without a contiguous host copy
+        dev = DeviceArray(arr.shape, arr.dtype)
+        check(_lib.load().mdx_memcpy_h2d_rows(dev.ptr, arr.ctypes.data, arr.shape[0],
+                                              arr.shape[1] * arr.strides[1], arr.strides[0]))
+        return dev.ptr, _dtype_code(arr.dtype), MDX_DEVICE, arr.shape, dev
     arr = np.ascontiguousarray(arr)
     return arr.ctypes.data, _dtype_code(arr.dtype), MDX_HOST, arr.shape, arr
+
+
+_ROWS_UPLOAD_MIN_BYTES = 8 << 20
+
+
+def _is_frame_range(arr: np.ndarray) -> bool:
+    """True for a large three-dimensional array whose rows ``arr[a]`` are contiguous but
+    lie further apart than their length (``stored[:, begin:end]``)."""
+    if arr.ndim != 3 or arr.flags.c_contiguous or arr.nbytes < _ROWS_UPLOAD_MIN_BYTES:
+        return False
+    item = arr.itemsize
+    return (arr.strides[2] == item and arr.strides[1] == arr.shape[2] * item
+            and arr.strides[0] > arr.shape[1] * arr.strides[1] and arr.shape[0] > 0)
 
 
 class Event:
@@ -307,7 +329,7 @@ def weighted_atom_sum(x: ArrayLike, scalar_weight: float = 1.0,
 
     ``out`` may be a float64 ``DeviceArray`` of shape ``(T, k)``: the series then stays
     in device memory (for a following ``map_coordinates`` / ``acf_windows``)."""
-    ptr, dt, loc, shape, keep = _as_input(x)
+    ptr, dt, loc, shape, keep = _as_input(x, rows=True)
     if len(shape) != 3:
         raise ValueError("x must have shape (n_atoms, n_frames, k)")
     n_atoms, n_frames, k = shape
@@ -332,7 +354,7 @@ def weighted_atom_sum(x: ArrayLike, scalar_weight: float = 1.0,
 
 def momentum_flux(stress: ArrayLike, out: Optional[np.ndarray] = None,
                   accumulate: bool = False) -> np.ndarray:
-    ptr, dt, loc, shape, keep = _as_input(stress)
+    ptr, dt, loc, shape, keep = _as_input(stress, rows=True)
     if len(shape) != 3 or shape[2] != 6:
         raise ValueError("stress must have shape (n_atoms, n_frames, 6)")
     out = _out_buffer(out, (shape[1], 3), accumulate)
@@ -483,7 +505,7 @@ def unwrap_coordinates(pos: ArrayLike, box, carry: Optional[dict] = None, out=No
                        out_dtype=np.float64):
     """Unwrap ``pos`` ``[N, T, 3]`` by jump detection; returns ``(unwrapped, carry)``
     with ``carry = {"last_pos": [N, 3], "last_image_box": [N, 3]}`` for the next batch."""
-    ptr, dt, loc, shape, keep = _as_input(pos)
+    ptr, dt, loc, shape, keep = _as_input(pos, rows=True)
     if len(shape) != 3 or shape[2] != 3:
         raise ValueError("pos must have shape (n_atoms, n_frames, 3)")
     n_atoms, n_frames = shape[0], shape[1]
@@ -566,7 +588,7 @@ def acf_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: in
 
     Returns ``(acf_sum, moments)``; ``moments`` is ``None`` without ``time``.
     """
-    ptr, dt, loc, shape, keep = _as_input(x)
+    ptr, dt, loc, shape, keep = _as_input(x, rows=True)
     if len(shape) != 3:
         raise ValueError("x must have shape (n_series, n_frames, k)")
     tau = _tau_array(tau)
@@ -645,7 +667,7 @@ def ccf_windows(a: ArrayLike, b: ArrayLike, correlation_time: int, win_begin: in
 def msd_windows(x: ArrayLike, correlation_time: int, win_begin: int, win_end: int, tau,
                 scale: float = 1.0) -> np.ndarray:
     """Windowed squared displacement sums of ``x`` ``[S, T, k]``; see ``mdx_msd_windows``."""
-    ptr, dt, loc, shape, keep = _as_input(x)
+    ptr, dt, loc, shape, keep = _as_input(x, rows=True)
     if len(shape) != 3:
         raise ValueError("x must have shape (n_series, n_frames, k)")
     tau = _tau_array(tau)

@@ -1,7 +1,9 @@
-import cProfile, pstats, sys, io
-sys.argv = ["time_calculators.py", "4000"]
+import cProfile, os, pstats, sys, io
+from_dir = os.path.dirname(os.path.abspath(__file__))
+frames = sys.argv[1] if len(sys.argv) > 1 else "4000"
+sys.argv = ["time_calculators.py", frames]
 ns = {}
-src = open("scratch/time_calculators.py").read()
+src = open(os.path.join(from_dir, "time_calculators.py")).read().replace("os.path.abspath(__file__)", repr(os.path.join(from_dir, "time_calculators.py")))
 head = src[:src.index('timed("RadialDistributionFunction(500')]
 exec(compile(head, "head", "exec"), ns)
 exp = ns["exp"]
@@ -10,5 +12,5 @@ for label, fn in (("GK self", lambda: exp.run.GreenKuboDiffusionCoefficients(dat
                   ("Einstein", lambda: exp.run.EinsteinDiffusionCoefficients(data_range=100, plot=False)),
                   ("ADF", lambda: exp.run.AngularDistributionFunction(number_of_configurations=50, cutoff=6.0, plot=False))):
     pr = cProfile.Profile(); pr.enable(); fn(); pr.disable()
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(8)
-    print("=====", label); print("\n".join(s.getvalue().splitlines()[0:20]))
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(12)
+    print("=====", label); print("\n".join(s.getvalue().splitlines()[0:26]))

@@ -1,6 +1,7 @@
 """End to end through the product API: a 10k-atom trajectory in the on-disk store
 (memory-mapped .npy), calculators run as a user would run them."""
 import os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import lammps_analysis_amd as mds
 from lammps_analysis_amd.database.mdsuite_properties import mdsuite_properties

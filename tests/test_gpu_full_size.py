@@ -105,6 +105,52 @@ def test_large_host_arrays_take_the_page_locked_upload_path(gpu):
     np.testing.assert_allclose(got, x.astype(np.float64).sum(axis=0), rtol=1e-12)
 
 
+def test_frame_ranges_of_host_arrays_are_uploaded_row_by_row(gpu, monkeypatch):
+    """A frame range ``stored[:, begin:end]`` of a larger host array (what the batch loader
+    hands to the per-atom calculators) goes to the device row by row through the
+    page-locked buffers, without a contiguous host copy: the bytes that arrive, and the
+    results of the entry points that take such a view, equal those of a copy.  Row lengths
+    that are no multiple of anything, more rows than one buffer holds, few long rows, and
+    (threshold lowered) small arrays."""
+    from lammps_analysis_amd import _lib
+    rng = np.random.default_rng(78)
+    lib = _lib.load()
+    for n_rows, n_frames, begin, end in ((700, 20_000, 37, 19_950),    # 167 MB: several buffers
+                                         (3, 9_000_000, 5, 8_999_999),   # rows longer than a buffer
+                                         (513, 1_000, 1, 999)):
+        stored = rng.integers(0, 2 ** 31, size=(n_rows, n_frames, 3), dtype=np.int32) \
+            .view(np.float32)
+        view = stored[:, begin:end]
+        dev = gpu.DeviceArray(view.shape, np.float32)
+        _lib.check(lib.mdx_memcpy_h2d_rows(dev.ptr, view.ctypes.data, n_rows,
+                                           view.shape[1] * view.strides[1], view.strides[0]))
+        np.testing.assert_array_equal(dev.to_numpy().view(np.int32),
+                                      np.ascontiguousarray(view).view(np.int32))
+        dev.free()
+        del stored, view
+    stored = np.cumsum(rng.normal(size=(400, 6_000, 3)), axis=1).astype(np.float32)  # 29 MB
+    view = stored[:, 100:5_900]
+    assert not view.flags.c_contiguous and gpu._is_frame_range(view)
+    copy = np.ascontiguousarray(view)
+    tau = np.arange(64)
+    for arrays in ((view, copy),):
+        a, b = arrays
+        np.testing.assert_array_equal(gpu.weighted_atom_sum(a, scalar_weight=-1.5),
+                                      gpu.weighted_atom_sum(b, scalar_weight=-1.5))
+        got, mom = gpu.acf_windows(a, 1, 0, 5_000, tau)
+        ref, ref_mom = gpu.acf_windows(b, 1, 0, 5_000, tau)
+        np.testing.assert_array_equal(got, ref)
+        np.testing.assert_array_equal(gpu.msd_windows(a, 1, 3, 5_000, tau),
+                                      gpu.msd_windows(b, 1, 3, 5_000, tau))
+        box = [50.0, 60.0, 70.0]
+        np.testing.assert_array_equal(gpu.unwrap_coordinates(a, box)[0],
+                                      gpu.unwrap_coordinates(b, box)[0])
+    monkeypatch.setattr(gpu, "_ROWS_UPLOAD_MIN_BYTES", 0)
+    tiny = stored[:7, 3:11]
+    np.testing.assert_array_equal(gpu.weighted_atom_sum(tiny),
+                                  gpu.weighted_atom_sum(np.ascontiguousarray(tiny)))
+
+
 @pytest.mark.parametrize("what,data_range", [("msd", 100), ("msd", 300), ("acf", 500)])
 def test_band_kernels_agree_at_size(gpu, monkeypatch, what, data_range):
     """Per-atom MSD / VACF of 3 000 atoms x 20 000 frames through the three band kernels
