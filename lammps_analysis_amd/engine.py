@@ -140,7 +140,7 @@ def uniform_fill_at(index: np.ndarray, seed: int, lo: float, hi: float) -> np.nd
     return (lo32 + (span * u).astype(np.float32)).astype(np.float32)
 
 
-def _as_input(x: ArrayLike, rows: bool = False):
+def _as_input(x: ArrayLike, rows: bool = False, any_size: bool = False):
     """(pointer, dtype code, location, shape, keepalive) of an input array.  ``rows``: a
     frame range of a larger host array may be uploaded here, row by row (entry points with a
     single array argument)."""
@@ -149,7 +149,7 @@ def _as_input(x: ArrayLike, rows: bool = False):
     arr = np.asarray(x)
     if arr.dtype not in (np.float32, np.float64):
         arr = arr.astype(np.float64)
-    if rows and _is_frame_range(arr):
+    if rows and _is_frame_range(arr, any_size):
         # a frame range of a stored [atoms][frames][k] array (what the batch loader hands
         # over): its rows go to the device as they lie, without a contiguous host copy
         dev = DeviceArray(arr.shape, arr.dtype)
@@ -160,13 +160,26 @@ def _as_input(x: ArrayLike, rows: bool = False):
     return arr.ctypes.data, _dtype_code(arr.dtype), MDX_HOST, arr.shape, arr
 
 
+def _as_inputs(arrays):
+    """``_as_input`` for the arrays of one call, which must end up in one place: frame
+    ranges are uploaded row by row only when every host array of the call is one."""
+    host = [np.asarray(a) for a in arrays if not isinstance(a, DeviceArray)]
+    rows = bool(host) and len(host) == len(arrays) and \
+        sum(h.nbytes for h in host) >= _ROWS_UPLOAD_MIN_BYTES and \
+        all(h.dtype in (np.float32, np.float64) and _is_frame_range(h, any_size=True)
+            for h in host)
+    return [_as_input(a, rows=rows, any_size=rows) for a in arrays]
+
+
 _ROWS_UPLOAD_MIN_BYTES = 8 << 20
 
 
-def _is_frame_range(arr: np.ndarray) -> bool:
+def _is_frame_range(arr: np.ndarray, any_size: bool = False) -> bool:
     """True for a large three-dimensional array whose rows ``arr[a]`` are contiguous but
     lie further apart than their length (``stored[:, begin:end]``)."""
-    if arr.ndim != 3 or arr.flags.c_contiguous or arr.nbytes < _ROWS_UPLOAD_MIN_BYTES:
+    if arr.ndim != 3 or arr.flags.c_contiguous:
+        return False
+    if not any_size and arr.nbytes < _ROWS_UPLOAD_MIN_BYTES:
         return False
     item = arr.itemsize
     return (arr.strides[2] == item and arr.strides[1] == arr.shape[2] * item
@@ -365,7 +378,7 @@ def momentum_flux(stress: ArrayLike, out: Optional[np.ndarray] = None,
 
 def thermal_flux(stress: ArrayLike, vel: ArrayLike, ke: ArrayLike, pe: ArrayLike,
                  out: Optional[np.ndarray] = None, accumulate: bool = False) -> np.ndarray:
-    infos = [_as_input(a) for a in (stress, vel, ke, pe)]
+    infos = _as_inputs((stress, vel, ke, pe))
     if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
         raise ValueError("all thermal-flux inputs must share dtype and location")
     n_atoms, n_frames = infos[0][3][0], infos[0][3][1]
@@ -384,7 +397,7 @@ def thermal_flux(stress: ArrayLike, vel: ArrayLike, ke: ArrayLike, pe: ArrayLike
 def energy_weighted_sum(x: ArrayLike, ke: ArrayLike, pe: ArrayLike,
                         out: Optional[np.ndarray] = None, accumulate: bool = False):
     """``out[t, :] (+)= sum_a x[a, t, :] * (ke[a, t] + pe[a, t])`` in float64."""
-    infos = [_as_input(a) for a in (x, ke, pe)]
+    infos = _as_inputs((x, ke, pe))
     if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
         raise ValueError("all inputs must share dtype and location")
     n_atoms, n_frames = infos[0][3][0], infos[0][3][1]
@@ -406,7 +419,7 @@ def kinaci_heat_current(pos: ArrayLike, vel: ArrayLike, force: ArrayLike, pe: Ar
     """``out[t, :] (+)= sum_a pos[a, t, :] * (I_a(t) + pe[a, t])`` with the running
     integral ``I_a(t) = carry[a] + dt * cumsum_t(force[a] . vel[a])``; see
     ``mdx_kinaci_heat_current``.  Returns ``(out, carry at the last frame)``."""
-    infos = [_as_input(a) for a in (pos, vel, force, pe)]
+    infos = _as_inputs((pos, vel, force, pe))
     if len({i[1] for i in infos}) != 1 or len({i[2] for i in infos}) != 1:
         raise ValueError("all inputs must share dtype and location")
     n_atoms, n_frames = infos[0][3][0], infos[0][3][1]

@@ -145,6 +145,24 @@ def test_frame_ranges_of_host_arrays_are_uploaded_row_by_row(gpu, monkeypatch):
         box = [50.0, 60.0, 70.0]
         np.testing.assert_array_equal(gpu.unwrap_coordinates(a, box)[0],
                                       gpu.unwrap_coordinates(b, box)[0])
+    # entry points with several arrays: all of them frame ranges of stored arrays
+    n, t = 300, 4_000
+    stress, vel, force = (rng.normal(size=(n, t, k)).astype(np.float32) for k in (6, 3, 3))
+    ke, pe = (rng.random((n, t, 1)).astype(np.float32) for _ in range(2))
+    cut = np.s_[:, 8:3_992]
+    views = [a[cut] for a in (stress, vel, force, ke, pe, stored[:n, :t])]
+    copies = [np.ascontiguousarray(v) for v in views]
+    assert all(gpu._is_frame_range(v, any_size=True) for v in views)
+    for a, b in ((views, copies),):
+        np.testing.assert_array_equal(gpu.thermal_flux(a[0], a[1], a[3], a[4]),
+                                      gpu.thermal_flux(b[0], b[1], b[3], b[4]))
+        np.testing.assert_array_equal(gpu.energy_weighted_sum(a[1], a[3], a[4]),
+                                      gpu.energy_weighted_sum(b[1], b[3], b[4]))
+        np.testing.assert_array_equal(gpu.kinaci_heat_current(a[5], a[1], a[2], a[4], 0.01)[0],
+                                      gpu.kinaci_heat_current(b[5], b[1], b[2], b[4], 0.01)[0])
+    # one contiguous array among them: everything stays on the host path
+    np.testing.assert_array_equal(gpu.energy_weighted_sum(copies[1], views[3], views[4]),
+                                  gpu.energy_weighted_sum(copies[1], copies[3], copies[4]))
     monkeypatch.setattr(gpu, "_ROWS_UPLOAD_MIN_BYTES", 0)
     tiny = stored[:7, 3:11]
     np.testing.assert_array_equal(gpu.weighted_atom_sum(tiny),
