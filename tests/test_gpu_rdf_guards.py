@@ -32,6 +32,10 @@ CLASSES = {
     "thin_box_long_cutoff": ((10.0, 40.0, 160.0), 60.0, 3000),
     "bins_at_lds_limit": ((65.0, 65.0, 65.0), 32.4, (1 << 14) - 3),
     "bins_power_of_two_minus_three": ((65.0, 65.0, 65.0), 32.4, (1 << 10) - 3),
+    # the position field holds nbins + 2 + 64 dump words: the last count that fits 2^12 and
+    # the first that needs 2^13
+    "bins_dump_words_just_fit": ((65.0, 65.0, 65.0), 32.4, (1 << 12) - 66),
+    "bins_dump_words_need_a_bit": ((65.0, 65.0, 65.0), 32.4, (1 << 12) - 65),
 }
 
 

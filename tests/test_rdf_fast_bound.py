@@ -46,8 +46,12 @@ GEOMETRIES = [
     ((7.3, 9.1, 8.2), 3.55, 355),
     ((65.0, 65.0, 65.0), 56.0, 2000),            # cutoff near the half diagonal
 ]
-# bin counts at 2^k - 3 (the mantissa split changes at nbins + 3 = 2^k) for k = 6..15
+# bin counts around the places where the mantissa split changes (the position field holds
+# the bins, the overflow bin and 64 dump words: nbins + 66 = 2^k) for k = 6..15; the last
+# of each group no longer fits k = 15 and is left to the table kernel
 GEOMETRIES += [((65.0, 65.0, 65.0), 32.4, (1 << k) - 3) for k in range(6, 16)]
+GEOMETRIES += [((65.0, 65.0, 65.0), 32.4, (1 << k) - 66) for k in range(8, 16)]
+GEOMETRIES += [((65.0, 65.0, 65.0), 32.4, (1 << k) - 65) for k in (8, 12, 15)]
 GEOMETRIES += [((10.0, 40.0, 160.0), 4.9, (1 << k) - 3) for k in (8, 12, 15)]
 GEOMETRIES += [((65.0, 65.0, 65.0), 32.4, (1 << k) - 2) for k in (7, 11, 14)]
 
