@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libmdx.so (built files are kept out of the history): build it
+    once where hipcc is at hand, so that the symbol and host-logic tests have the library
+    they check.  An existing library is left alone, whatever its age."""
+    import shutil
+
+    from lammps_analysis_amd import build
+    if not build.LIB_PATH.exists() and (shutil.which("hipcc") or
+                                        pathlib.Path("/opt/rocm/bin/hipcc").exists()):
+        build.build_library()
+
+
 def _gpu_available() -> bool:
     try:
         from lammps_analysis_amd import _lib
