@@ -108,6 +108,10 @@ struct RdfParams {
   uint32_t fast_dump_bits;   // bits of position nbins + 1 with every fraction bit set
   int fast_ok;               // 0: the bound is too wide for this geometry, do not use
   float cull_gap2;           // tile pairs with a squared box gap above this hold no pair in reach
+  int cull_on;               // sorted frames: skip what the boxes put out of reach
+#ifdef MDX_TIMING_SWITCHES
+  int timing_mask;           // >= 0: every quarter takes this loop variant (wrong counts)
+#endif
 };
 
 // ---------------------------------------------------------------- pack kernel
@@ -170,7 +174,6 @@ struct SortSpecies {
   int32_t cell_bits;   // cells per axis = 1 << cell_bits (at most 4)
 };
 
-constexpr int kSortMaxCells = 4096;
 // Position of every cell along a Hilbert curve, for grids of 2, 4, 8 and 16 cells per axis
 // back to back (8 + 64 + 512 + 4096 entries); entry = rank of cell (z * g + y) * g + x.
 constexpr int kCurveEntries = 8 + 64 + 512 + 4096;
@@ -183,22 +186,32 @@ __host__ __device__ inline int curve_offset(int cell_bits) {
 // then the bounding boxes of every tile of the sorted frame and of its four quarters of 64
 // slots.  boxes: per frame [5][n_tiles][...]: n_tiles tile boxes, then 4 n_tiles quarter
 // boxes, six floats each (lowest corner, highest corner); a quarter without atoms gets
-// (+inf, -inf), which is out of everybody's reach.  The order of atoms
-// within a cell is whatever the atomics make it; no result depends on it.  frame_lo holds
-// the frame's smallest coordinate per component (the frame is compact: every coordinate
-// lies within one box length above it), so the cell grid follows a trajectory that is not
-// wrapped into [0, L).  Frames that are not compact are copied unsorted (they go to the
-// table kernel, which skips nothing); their boxes are never read.
+// (+inf, -inf), which is out of everybody's reach.
+// The sorted order is a function of the frame alone (within a cell: the order of the
+// input), never of the timing of the block's threads: ranks that share the tile pairs of
+// a frame sort it each for themselves, and their tiles must hold the same atoms.  So the
+// four waves take a quarter of the atoms each, in input order, with a table of cell
+// counts per wave: counts first (LDS atomics, whose order does not matter), then every
+// wave's first position per cell (cells in curve order, within a cell wave by wave),
+// then the placement, 64 atoms at a time -- the lanes that share a cell are found with
+// ballots, lowest lane first, and take consecutive positions.
+// frame_lo holds the frame's smallest coordinate per component (the frame is compact:
+// every coordinate lies within one box length above it), so the cell grid follows a
+// trajectory that is not wrapped into [0, L).  Frames that are not compact are copied
+// unsorted (they go to the table kernel, which skips nothing); their boxes are never read.
+// Dynamic LDS: uint32 [5][n_cells].
 __global__ __launch_bounds__(256) void rdf_sort_kernel(
     const float *__restrict__ packed, float *__restrict__ sorted, int64_t n_pad, int n_tiles,
     const SortSpecies *__restrict__ species, const int32_t *__restrict__ frame_wrapped,
     const float *__restrict__ frame_lo, const uint16_t *__restrict__ curve, RdfParams p,
     float *__restrict__ boxes) {
-  __shared__ uint32_t cell_count[kSortMaxCells];
+  extern __shared__ __align__(16) uint32_t sort_lds[];
   __shared__ uint32_t wave_total[4];
   const SortSpecies sp = species[blockIdx.x];
   const int f = blockIdx.y;
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad + sp.first_slot;
   float *Y = sorted + static_cast<int64_t>(f) * 3 * n_pad + sp.first_slot;
   const int slots = sp.tiles * kTile;
@@ -209,7 +222,9 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   }
   const int n_cells = 1 << (3 * sp.cell_bits);
   const uint32_t per_axis = 1u << sp.cell_bits;
-  for (int i = tid; i < n_cells; i += 256) cell_count[i] = 0u;
+  uint32_t *cell_count = sort_lds;                        // all atoms of a cell
+  uint32_t *own = sort_lds + (1 + wave) * n_cells;        // this wave's atoms of a cell
+  for (int i = tid; i < 5 * n_cells; i += 256) sort_lds[i] = 0u;
   __syncthreads();
   const uint16_t *rank_of_cell = curve + curve_offset(sp.cell_bits);
   float lo[3], scale[3];
@@ -227,36 +242,69 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
     }
     return rank_of_cell[(((q[2] << sp.cell_bits) | q[1]) << sp.cell_bits) | q[0]];
   };
-  for (int i = tid; i < sp.used; i += 256) atomicAdd(&cell_count[cell_of(i)], 1u);
+  // the wave's atoms: a quarter of the species, in whole groups of 64
+  const int per_wave = ((sp.used + 255) / 256) * 64;
+  const int w_begin = min(sp.used, wave * per_wave);
+  const int w_end = min(sp.used, w_begin + per_wave);
+  for (int i = w_begin + lane; i < w_end; i += 64) atomicAdd(&own[cell_of(i)], 1u);
   __syncthreads();
-  // exclusive scan of the cell counts: 16 cells per thread at most
+  // exclusive scan over the cells' totals (16 cells per thread at most), then the first
+  // position of every wave within the cell
   {
     const int per_thread = (n_cells + 255) / 256;
     const int c0 = tid * per_thread;
     uint32_t sum = 0;
     for (int k = 0; k < per_thread; ++k)
-      if (c0 + k < n_cells) sum += cell_count[c0 + k];
+      if (c0 + k < n_cells) {
+        uint32_t n = 0;
+        for (int w = 0; w < 4; ++w) n += sort_lds[(1 + w) * n_cells + c0 + k];
+        cell_count[c0 + k] = n;
+        sum += n;
+      }
     uint32_t incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t below = __shfl_up(incl, off);
-      if ((tid & 63) >= off) incl += below;
+      if (lane >= off) incl += below;
     }
-    if ((tid & 63) == 63) wave_total[tid >> 6] = incl;
+    if (lane == 63) wave_total[tid >> 6] = incl;
     __syncthreads();
     uint32_t base = incl - sum;
     for (int w = 0; w < (tid >> 6); ++w) base += wave_total[w];
     for (int k = 0; k < per_thread; ++k)
       if (c0 + k < n_cells) {
-        const uint32_t n = cell_count[c0 + k];
-        cell_count[c0 + k] = base;
-        base += n;
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t n = sort_lds[(1 + w) * n_cells + c0 + k];
+          sort_lds[(1 + w) * n_cells + c0 + k] = base;
+          base += n;
+        }
       }
   }
   __syncthreads();
-  for (int i = tid; i < sp.used; i += 256) {
-    const uint32_t dst = atomicAdd(&cell_count[cell_of(i)], 1u);
+  for (int i0 = w_begin; i0 < w_end; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < w_end;
+    const uint32_t cell = valid ? cell_of(i) : 0xFFFFFFFFu;
+    // the wave's next free position in the lane's cell (the wave's LDS operations keep
+    // their order, so the previous group's updates are in)
+    const uint32_t start = valid ? own[cell] : 0u;
+    uint32_t dst = 0u;
+    unsigned long long remaining = __ballot(valid);
+    while (remaining != 0ull) {
+      const int leader = __builtin_ctzll(remaining);
+      const uint32_t c0 = static_cast<uint32_t>(
+          __builtin_amdgcn_readlane(static_cast<int>(cell), leader));
+      const uint32_t first = static_cast<uint32_t>(
+          __builtin_amdgcn_readlane(static_cast<int>(start), leader));
+      const unsigned long long same = __ballot(cell == c0);
+      if (cell == c0)
+        dst = first + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+      if (lane == leader) own[c0] = first + static_cast<uint32_t>(__popcll(same));
+      remaining &= ~same;
+    }
+    if (valid) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Y[c * n_pad + dst] = X[c * n_pad + i];
+      for (int c = 0; c < 3; ++c) Y[c * n_pad + dst] = X[c * n_pad + i];
+    }
   }
   const float nan = __builtin_nanf("");
   for (int i = sp.used + tid; i < slots; i += 256)
@@ -520,11 +568,13 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
 // the same bits.
 __device__ __forceinline__ uint32_t fast_position_bits(float xi, float yi, float zi, float xj,
                                                        float yj, float zj, float hx, float hy,
-                                                       float hz, float scale, float magic) {
+                                                       float hz, float scale, float magic,
+                                                       int fold) {
   const float rx = xj - xi, ry = yj - yi, rz = zj - zi;
-  const float mx = hx - fabsf(fabsf(rx) - hx);
-  const float my = hy - fabsf(fabsf(ry) - hy);
-  const float mz = hz - fabsf(fabsf(rz) - hz);
+  // bit c of `fold` clear: the hot loop took component c as it is (fold_mask)
+  const float mx = (fold & 1) ? hx - fabsf(fabsf(rx) - hx) : rx;
+  const float my = (fold & 2) ? hy - fabsf(fabsf(ry) - hy) : ry;
+  const float mz = (fold & 4) ? hz - fabsf(fabsf(rz) - hz) : rz;
   const float s = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
   return __float_as_uint(__builtin_fmaf(__builtin_amdgcn_sqrtf(s), scale, magic));
 }
@@ -570,22 +620,24 @@ __device__ __forceinline__ void lds_count(uint32_t byte_offset, uint32_t value) 
 }
 
 constexpr int kQueueSlots = 8;  // near-edge pairs a lane can note before they are resolved
+constexpr int kQueueBytes = 2 * kQueueSlots;  // per lane: 16-bit entries
 
 // Resolves the noted pairs of every lane: the hot loop has already counted them in the
 // bin of the approximate position (if that was below the cutoff); here the literal
 // squared distance decides, and the count is moved when the two disagree.
 __device__ __forceinline__ void fast_resolve_queue(
-    int &count, uint8_t *__restrict__ queue, float xi, float yi, float zi,
+    int &count, uint16_t *__restrict__ queue, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
     float hx, float hy, float hz, float scale, float magic, uint32_t *__restrict__ hist,
     const float *__restrict__ g_thr, const RdfParams &p) {
   while (__any(count > 0)) {
     if (count > 0) {
       --count;
-      const int j = queue[count];
+      const int entry = queue[count];  // j-atom | components the hot loop folded << 8
+      const int j = entry & 255;
       const float pxj = xj[j], pyj = yj[j], pzj = zj[j];
       const uint32_t bits =
-          fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic);
+          fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic, entry >> 8);
       const bool counted = bits < p.fast_keep_bits;
       const int guess = static_cast<int>((bits & 0x7FFFFFu) >> p.fast_frac_bits);
       const float s = literal_wrapped_s(xi, yi, zi, pxj, pyj, pzj, p);
@@ -603,11 +655,11 @@ __device__ __forceinline__ void fast_resolve_queue(
 
 // The j-atoms [j_begin, j_end) of one (tile pair, frame) item: lane = i-atom.  Near-edge
 // pairs are noted in the lane's queue (`count` entries so far) for the caller to resolve.
-template <bool kDiag>
+template <bool kDiag, int kFold = 7>
 __device__ __forceinline__ void fast_j_range(
     int j_begin, int j_end, int &count, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
-    uint32_t *__restrict__ hist, uint8_t *__restrict__ queue, const float *__restrict__ g_thr,
+    uint32_t *__restrict__ hist, uint16_t *__restrict__ queue, const float *__restrict__ g_thr,
     const RdfParams &p, int tid, float hx, float hy, float hz, float scale, float magic,
     uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
   const uint32_t shift = in_vgpr(p.fast_frac_bits - 2u);
@@ -635,12 +687,24 @@ __device__ __forceinline__ void fast_j_range(
       const v2f ry = v2f{pys[2 * h], pys[2 * h + 1]} - yi2;
       const v2f rz = v2f{pzs[2 * h], pzs[2 * h + 1]} - zi2;
       v2f mx, my, mz;
-      mx.x = fold_half(rx.x, hx);
-      mx.y = fold_half(rx.y, hx);
-      my.x = fold_half(ry.x, hy);
-      my.y = fold_half(ry.y, hy);
-      mz.x = fold_half(rz.x, hz);
-      mz.y = fold_half(rz.y, hz);
+      if (kFold & 1) {
+        mx.x = fold_half(rx.x, hx);
+        mx.y = fold_half(rx.y, hx);
+      } else {
+        mx = rx;
+      }
+      if (kFold & 2) {
+        my.x = fold_half(ry.x, hy);
+        my.y = fold_half(ry.y, hy);
+      } else {
+        my = ry;
+      }
+      if (kFold & 4) {
+        mz.x = fold_half(rz.x, hz);
+        mz.y = fold_half(rz.y, hz);
+      } else {
+        mz = rz;
+      }
       const v2f s2 = __builtin_elementwise_fma(mz, mz, __builtin_elementwise_fma(my, my, mx * mx));
       const v2f root = {__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};
       const v2f t2 = __builtin_elementwise_fma(root, scale2, magic2);
@@ -662,7 +726,7 @@ __device__ __forceinline__ void fast_j_range(
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (near[u]) {
-          queue[count] = static_cast<uint8_t>(j0 + u);
+          queue[count] = static_cast<uint16_t>((j0 + u) | (kFold << 8));
           ++count;
         }
       }
@@ -679,7 +743,7 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one) {
   const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
@@ -692,24 +756,81 @@ __device__ __forceinline__ void fast_tile_loop(
                      g_thr, p);
 }
 
-// The same for a sorted frame and two different tiles: the wave's 64 i-atoms and each
-// quarter of the j-tile have bounding boxes of their own (ibox, jboxes[4]), and a quarter
-// out of the wave's reach is skipped.  The branch is uniform over the wave.
-__device__ __forceinline__ void fast_tile_loop_quarters(
+// Which components of the pairs (64 i-atoms in ibox, 64 j-atoms in jbox) need the
+// minimum-image fold: bit c is clear when every difference x_j - x_i of component c lies
+// within [-L_c/2, L_c/2].  The boxes are the exact extremes of the float32 coordinates and
+// float32 subtraction is monotone, so fl(x_j - x_i) <= fl(jhi - ilo) <= L_c/2 (and likewise
+// the other way round): the literal rule then rounds r / L_c to zero and keeps r itself, and
+// so does the loop variant without the fold -- for such a component it is not an
+// approximation at all.  An empty box is (+inf, -inf); its differences are -inf (or NaN,
+// which compares false and asks for the fold), and its atoms are NaN padding either way.
+__device__ __forceinline__ int fold_mask(const float *__restrict__ ibox,
+                                         const float *__restrict__ jbox, float hx, float hy,
+                                         float hz) {
+  const float h[3] = {hx, hy, hz};
+  int mask = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const bool inside = (jbox[3 + c] - ibox[c] <= h[c]) && (ibox[3 + c] - jbox[c] <= h[c]);
+    mask |= inside ? 0 : (1 << c);
+  }
+  return __builtin_amdgcn_readfirstlane(mask);
+}
+
+// One (tile pair, frame) item of a sorted frame: the wave's 64 i-atoms and each quarter of
+// the j-tile have bounding boxes of their own (ibox, jboxes[4]).  Per quarter the wave
+// picks the loop variant that folds only the components that can need it, and, with a
+// short cutoff (p.cull_on), skips a quarter out of its reach.  All branches are uniform
+// over the wave.  In a diagonal tile pair a wave starts at its own quarter, where only
+// j > i counts.
+template <bool kDiag>
+__device__ __forceinline__ void fast_tile_loop_sorted(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one, const float *__restrict__ ibox,
     const float *__restrict__ jboxes) {
   const int j_end = (j_count + 3) & ~3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int count = 0;
-  for (int q = 0; q < kTile / 64; ++q) {
+  for (int q = kDiag ? wave : 0; q < kTile / 64; ++q) {
     const int lo = 64 * q;
     if (lo >= j_end) break;
-    if (box_gap2(ibox, jboxes + 6 * q, p) > p.cull_gap2) continue;
-    fast_j_range<false>(lo, min(j_end, lo + 64), count, xi, yi, zi, xj, yj, zj, hist, queue,
-                        g_thr, p, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+    const int hi = min(j_end, lo + 64);
+    const float *jbox = jboxes + 6 * q;
+    if (!kDiag && p.cull_on && box_gap2(ibox, jbox, p) > p.cull_gap2) continue;
+#ifdef MDX_TIMING_SWITCHES
+    const int mask = p.timing_mask >= 0 ? p.timing_mask : fold_mask(ibox, jbox, hx, hy, hz);
+#else
+    const int mask = fold_mask(ibox, jbox, hx, hy, hz);
+#endif
+    if (kDiag && q == wave) {
+      // the wave's own quarter: one box on both sides, as a rule narrower than half the box
+      if (mask == 0)
+        fast_j_range<true, 0>(lo, hi, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid,
+                              hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+      else
+        fast_j_range<true, 7>(lo, hi, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid,
+                              hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+      continue;
+    }
+#define MDX_FOLD_CASE(M)                                                                     \
+  case M:                                                                                    \
+    fast_j_range<false, M>(lo, hi, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid, \
+                           hx, hy, hz, scale, magic, addr_mask, frac_mask, one);            \
+    break;
+    switch (mask) {
+      MDX_FOLD_CASE(0)
+      MDX_FOLD_CASE(1)
+      MDX_FOLD_CASE(2)
+      MDX_FOLD_CASE(3)
+      MDX_FOLD_CASE(4)
+      MDX_FOLD_CASE(5)
+      MDX_FOLD_CASE(6)
+      MDX_FOLD_CASE(7)
+    }
+#undef MDX_FOLD_CASE
   }
   fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
                      g_thr, p);
@@ -728,7 +849,7 @@ __device__ __forceinline__ void fast_tile_loop_quarters(
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
 // pace.  Frames that are not "compact" are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] (bins, the overflow bin, kDumpWords dump words) |
-// uint8 queue[kTile][kQueueSlots] | uint32 claim.
+// uint16 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
 // The loop needs every wave a SIMD can hold to hide its dependent chains (sub, sub, mul,
@@ -746,9 +867,10 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   const int tid = threadIdx.x;
-  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueSlots;
+  uint16_t *queue = reinterpret_cast<uint16_t *>(
+      lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueBytes);
   uint32_t *claim = reinterpret_cast<uint32_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words) +
-                                                 static_cast<size_t>(kTile) * kQueueSlots);
+                                                 static_cast<size_t>(kTile) * kQueueBytes);
 
   const float hx = in_vgpr(p.half_box[0]);
   const float hy = in_vgpr(p.half_box[1]);
@@ -815,8 +937,8 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
       for (int f = f_begin; f < f_end; ++f) {
         if (frame_wrapped[f] != 2) continue;  // compact frames only, see rdf_fast_setup
-        if (boxes != nullptr && !tp.diagonal) {
-          // sorted frames: the two tiles' boxes are further apart than any pair that counts
+        if (boxes != nullptr && p.cull_on && !tp.diagonal) {
+          // short cutoff: the two tiles' boxes are further apart than any pair that counts
           const float *fb = boxes + static_cast<int64_t>(f) * 5 * n_tiles * 6;
           if (box_gap2(fb + tp.tile_i * 6, fb + tp.tile_j * 6, p) > p.cull_gap2) continue;
         }
@@ -827,17 +949,23 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const float *xj = X + static_cast<int64_t>(tp.tile_j) * kTile;
         const float *yj = xj + n_pad;
         const float *zj = yj + n_pad;
-        if (tp.diagonal)
-          fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
-                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
-        else if (boxes != nullptr) {
+        if (boxes != nullptr) {
           const float *quarters = boxes + (static_cast<int64_t>(f) * 5 + 1) * n_tiles * 6;
           const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-          fast_tile_loop_quarters(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
-                                  hx, hy, hz, scale, magic, addr_mask, frac_mask, one,
-                                  quarters + (tp.tile_i * 4 + wave) * 6,
-                                  quarters + tp.tile_j * 4 * 6);
-        } else
+          const float *ibox = quarters + (tp.tile_i * 4 + wave) * 6;
+          const float *jboxes = quarters + tp.tile_j * 4 * 6;
+          if (tp.diagonal)
+            fast_tile_loop_sorted<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p,
+                                        tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one,
+                                        ibox, jboxes);
+          else
+            fast_tile_loop_sorted<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr,
+                                         p, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask,
+                                         one, ibox, jboxes);
+        } else if (tp.diagonal)
+          fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+        else
           fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
                                 hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       }
@@ -1167,8 +1295,10 @@ struct mdx_rdf_s {
   size_t lds_bytes = 0;
   DeviceBuffer d_pairs, d_pairs_shard, d_hist, d_thresholds, d_slot_species, d_slot_atom;
   DeviceBuffer d_species_ptr, d_frames, d_packed, d_wrapped, d_counter;
-  // short cutoffs: frames sorted in space, tile boxes, tile pairs out of reach skipped
-  bool cull = false;
+  // frames sorted in space with boxes per tile and per 64 slots: the fast kernel leaves out
+  // the fold of components that cannot need it and, for a short cutoff, what is out of reach
+  bool sort_frames = false;
+  size_t sort_lds_bytes = 0;  // rdf_sort_kernel: five tables of the finest grid's cells
   int n_sort_species = 0;
   DeviceBuffer d_sorted, d_boxes, d_frame_lo, d_sort_species, d_curve;
   int fast_blocks = 0;             // persistent grid of the fast kernel
@@ -1219,9 +1349,9 @@ int upload_shard(mdx_rdf_s *h, int rank, int count, hipStream_t stream) {
 
 namespace {
 
-// Buffers of the spatially sorted copy of `frames` packed frames (no-op without culling).
+// Buffers of the spatially sorted copy of `frames` packed frames (no-op without sorting).
 int reserve_sorted_frames(mdx_rdf_s *h, int64_t frames) {
-  if (!h->cull) return MDX_OK;
+  if (!h->sort_frames) return MDX_OK;
   const size_t n = static_cast<size_t>(frames);
   MDX_TRY(h->d_sorted.reserve(sizeof(float) * 3 * static_cast<size_t>(h->n_pad) * n));
   MDX_TRY(h->d_boxes.reserve(sizeof(float) * 6 * 5 * static_cast<size_t>(h->n_tiles) * n + 16));
@@ -1256,21 +1386,22 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
   if (h->n_pairs_shard == 0) return MDX_OK;
   const bool fast = !literal && h->params.fast_ok != 0 &&
                     (h->flags & MDX_RDF_TABLE_KERNEL) == 0u && h->fast_blocks > 0;
-  const bool cull = fast && h->cull && h->n_sort_species > 0;
+  const bool sorted = fast && h->sort_frames && h->n_sort_species > 0;
   if (!literal) {
     hipLaunchKernelGGL(rdf_extent_kernel, dim3(static_cast<unsigned>(nf)), dim3(256), 0,
                        stream, h->d_packed.as<float>(), h->n_pad, h->params,
-                       h->d_wrapped.as<int32_t>(), cull ? h->d_frame_lo.as<float>() : nullptr);
+                       h->d_wrapped.as<int32_t>(), sorted ? h->d_frame_lo.as<float>() : nullptr);
     MDX_HIP(hipGetLastError());
   }
   // the image the pair kernels read: the packed frames, or their spatially sorted copy
   const float *image = h->d_packed.as<float>();
   const float *boxes = nullptr;
-  if (cull) {
+  if (sorted) {
     KernelTimer sort_timer(MDX_SLOT_RDF_PACK, stream);
     hipLaunchKernelGGL(rdf_sort_kernel,
                        dim3(static_cast<unsigned>(h->n_sort_species), static_cast<unsigned>(nf)),
-                       dim3(256), 0, stream, h->d_packed.as<float>(), h->d_sorted.as<float>(),
+                       dim3(256), h->sort_lds_bytes, stream, h->d_packed.as<float>(),
+                       h->d_sorted.as<float>(),
                        h->n_pad, static_cast<int>(h->n_tiles), h->d_sort_species.as<SortSpecies>(),
                        h->d_wrapped.as<int32_t>(), h->d_frame_lo.as<float>(),
                        h->d_curve.as<uint16_t>(), h->params, h->d_boxes.as<float>());
@@ -1566,17 +1697,20 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   }
 
   std::vector<SortSpecies> sort_table;
-  // Short cutoff against the box: sort the frames in space and skip what is out of reach
-  // (whole tile pairs, and quarters of a j-tile per wave).  The 64 atoms of a wave or of a
-  // quarter, of a species with n atoms, fill about the 64/n-th part of the box; skipping can
-  // only pay when the cutoff plus the edge of such a group stays well below half the box
-  // (measured: 10k-atom melt in a 65 box, cutoff 10: 74 k instead of 57 k frames/s; 100k-atom
-  // water box, cutoff 10: 4.4 k instead of 0.6 k).  MDX_RDF_CULL=0/1 overrides the choice
-  // (the counts do not change).
+  // Frames sorted in space serve two ends.  (1) Short cutoff against the box: skip what is
+  // out of reach (whole tile pairs, and quarters of a j-tile per wave).  The 64 atoms of a
+  // wave or of a quarter, of a species with n atoms, fill about the 64/n-th part of the box;
+  // skipping can only pay when the cutoff plus the edge of such a group stays well below
+  // half the box (measured: 10k-atom melt in a 65 box, cutoff 10: 74 k instead of 57 k
+  // frames/s; 100k-atom water box, cutoff 10: 4.4 k instead of 0.6 k).  (2) Any cutoff: a
+  // component in which two such groups lie within half a box length of each other needs no
+  // minimum-image fold (fold_mask), which pays as soon as the groups are small against the
+  // box (10k-atom melt: 56 % of the components).  MDX_RDF_CULL=0/1 and MDX_RDF_UNFOLD=0/1
+  // override the choices (the counts do not change).
   {
     const double volume = static_cast<double>(box[0]) * box[1] * box[2];
     const double shortest = std::min({box[0], box[1], box[2]});
-    bool worth = false;
+    bool worth = false, unfold = false;
     std::vector<SortSpecies> table;
     for (int s = 0; s < n_species; ++s) {
       if (tile_count[s] == 0) continue;
@@ -1592,10 +1726,21 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
       table.push_back(sp);
       const double group_edge = std::cbrt(volume * std::min<double>(1.0, 64.0 / used));
       if (tile_count[s] >= 8 && cutoff + group_edge < 0.45 * shortest) worth = true;
+      if (tile_count[s] >= 8 && group_edge < 0.3 * shortest) unfold = true;
     }
     if (const char *env = getenv("MDX_RDF_CULL")) worth = atoi(env) != 0;
-    h->cull = worth && !table.empty() && (flags & MDX_RDF_LITERAL_KERNEL) == 0u;
-    if (h->cull) sort_table = table;  // uploaded with the other device tables below
+    if (const char *env = getenv("MDX_RDF_UNFOLD")) unfold = atoi(env) != 0;
+    h->sort_frames =
+        (worth || unfold) && !table.empty() && (flags & MDX_RDF_LITERAL_KERNEL) == 0u;
+    p.cull_on = (h->sort_frames && worth) ? 1 : 0;
+    if (h->sort_frames) sort_table = table;  // uploaded with the other device tables below
+    for (const SortSpecies &sp : sort_table)
+      h->sort_lds_bytes =
+          std::max(h->sort_lds_bytes, sizeof(uint32_t) * 5 * (size_t(1) << (3 * sp.cell_bits)));
+    if (h->sort_lds_bytes > 0)
+      MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_sort_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(h->sort_lds_bytes)));
     // A skipped tile pair must hold no pair the literal rule would count.  Its pairs are
     // at least the box gap apart; the literal float32 distance is below the true one by
     // a few 2^-24 of itself plus 2^-24 of the box per component at most, and the gap's
@@ -1631,7 +1776,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
   if (!literal && p.fast_ok) {
     h->fast_lds_hist_words = (nbins + 1 + kDumpWords + 3) & ~3;
     h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
-                        static_cast<size_t>(kTile) * kQueueSlots + 16;
+                        static_cast<size_t>(kTile) * kQueueBytes + 16;
     if (h->fast_lds_bytes <= 160 * 1024) {
       MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_fast_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1648,6 +1793,7 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 #ifdef MDX_TIMING_SWITCHES
       // builds for timing experiments only: without the near-edge test the counts are wrong
       if (getenv("MDX_RDF_FAST_NO_EDGE")) p.fast_edge_units = 0;
+      p.timing_mask = getenv("MDX_RDF_TIMING_MASK") ? atoi(getenv("MDX_RDF_TIMING_MASK")) : -1;
 #endif
       if (getenv("MDX_RDF_DEBUG"))
         fprintf(stderr, "rdf fast: %d blocks/CU, %d CUs, lds %zu, edge units %u of %u\n", per_cu,
@@ -1821,7 +1967,7 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
 
   // frames are processed in chunks bounded by the packed image size
   const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
-  int64_t chunk = static_cast<int64_t>((size_t(h->cull ? 1 : 2) << 30) / bytes_per_frame);
+  int64_t chunk = static_cast<int64_t>((size_t(h->sort_frames ? 1 : 2) << 30) / bytes_per_frame);
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 32768) chunk = 32768;

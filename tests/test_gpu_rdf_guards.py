@@ -95,14 +95,19 @@ def test_lds_bins_are_flushed_before_they_wrap(gpu, monkeypatch):
 
 
 def _culled_and_not(gpu, monkeypatch, n_per_species, box, cutoff, nbins, pos, strict):
+    """Histograms with the frames sorted in space for skipping, for leaving out folds, for
+    both, and not sorted at all."""
     out = {}
-    for name, value in (("culled", "1"), ("all_pairs", "0")):
-        monkeypatch.setenv("MDX_RDF_CULL", value)
+    for name, cull, unfold in (("culled", "1", "1"), ("culled_every_fold", "1", "0"),
+                               ("unfolded", "0", "1"), ("all_pairs", "0", "0")):
+        monkeypatch.setenv("MDX_RDF_CULL", cull)
+        monkeypatch.setenv("MDX_RDF_UNFOLD", unfold)
         eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins, strict_reference_masks=strict)
         eng.accumulate(pos)
         out[name] = eng.read()
         eng.close()
     monkeypatch.delenv("MDX_RDF_CULL")
+    monkeypatch.delenv("MDX_RDF_UNFOLD")
     return out
 
 
@@ -146,8 +151,8 @@ def test_short_cutoff_path_skips_no_pair(gpu, monkeypatch, case):
     ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, list(box), cutoff, nbins,
                             strict=strict)
     got = _culled_and_not(gpu, monkeypatch, n_per_species, list(box), cutoff, nbins, pos, strict)
-    np.testing.assert_array_equal(got["all_pairs"], ref)
-    np.testing.assert_array_equal(got["culled"], ref)
+    for name in ("all_pairs", "culled", "culled_every_fold", "unfolded"):
+        np.testing.assert_array_equal(got[name], ref, err_msg=name)
     assert ref.sum() > 0
 
 
@@ -156,6 +161,7 @@ def test_short_cutoff_path_is_chosen_by_the_geometry(gpu, monkeypatch):
     the box and the species have tiles to skip, and only then; either way the counts are
     the oracle's.  20 000 atoms, cutoff 6 in a box of 60: most tile pairs are out of reach."""
     monkeypatch.delenv("MDX_RDF_CULL", raising=False)
+    monkeypatch.delenv("MDX_RDF_UNFOLD", raising=False)
     rng = np.random.default_rng(11)
     n_per_species, box = [7000, 13000], [60.0, 60.0, 60.0]
     pos = [(rng.random((n, 2, 3)) * 60.0).astype(np.float32) for n in n_per_species]
@@ -166,3 +172,67 @@ def test_short_cutoff_path_is_chosen_by_the_geometry(gpu, monkeypatch):
         eng.close()
         ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
         np.testing.assert_array_equal(got, ref)
+
+
+@pytest.mark.parametrize("case", ["half_a_box_apart", "planes", "rectangular", "drifted",
+                                  "small_species"])
+def test_components_without_the_fold_match_the_oracle(gpu, monkeypatch, case):
+    """Sorted frames, long cutoff: the pair loop leaves out the minimum-image fold of a
+    component when the boxes of the two 64-atom groups say that no difference exceeds half
+    a box length.  Cases around that limit: two sheets of atoms exactly and almost half a
+    box apart (differences of exactly L/2, which the literal rule does not fold, next to
+    differences one float above, which it does), atoms on a few planes (groups of zero
+    extent), a rectangular box (the limit differs per component), a trajectory far from
+    the origin, a species of less than one group beside a large one."""
+    rng = np.random.default_rng(sum(map(ord, case)) + 5)
+    n_per_species, frames = [4200, 3100], 3
+    box = np.array([36.0, 36.0, 36.0], np.float32)
+    cutoff, nbins = np.float32(17.9), 1790
+    if case == "rectangular":
+        box = np.array([20.0, 36.0, 90.0], np.float32)
+        cutoff, nbins = np.float32(9.9), 990
+    if case == "small_species":
+        n_per_species = [6000, 41]
+    pos = [(rng.random((n, frames, 3)) * box).astype(np.float32) for n in n_per_species]
+    if case == "half_a_box_apart":
+        half = np.float32(18.0)
+        for p in pos:
+            sheet = rng.integers(0, 4, p.shape[0])
+            jitter = (rng.integers(-2, 3, p.shape[:2]) * np.float32(2.0 ** -20)).astype(np.float32)
+            # x on two sheets exactly half a box apart, a few ulps around them
+            p[:, :, 0] = np.where((sheet % 2 == 0)[:, None], np.float32(4.0), np.float32(4.0) + half) + jitter
+            # y on two sheets a little less than half a box apart
+            p[:, :, 1] = np.where((sheet // 2 == 0)[:, None], np.float32(1.0), np.float32(18.75))
+    elif case == "planes":
+        for p in pos:
+            p[:, :, 2] = (rng.integers(0, 6, p.shape[:2]) * np.float32(6.0)).astype(np.float32)
+            p[:, :, 0] = np.round(p[:, :, 0] * 2) / 2
+    elif case == "drifted":
+        for p in pos:
+            p += np.array([1000.0, -250.5, 36.0], np.float32)
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, list(box), cutoff, nbins,
+                            strict=True)
+    got = _culled_and_not(gpu, monkeypatch, n_per_species, list(box), cutoff, nbins, pos, True)
+    for name in ("all_pairs", "unfolded", "culled"):
+        np.testing.assert_array_equal(got[name], ref, err_msg=name)
+    assert ref.sum() > 0
+
+
+@pytest.mark.parametrize("cutoff,nbins", [(np.float32(5.0), 500), (np.float32(19.9), 1990)])
+def test_sorted_frames_with_the_tile_pairs_sharded(gpu, monkeypatch, cutoff, nbins):
+    """Ranks that share the tile pairs of a frame sort it each for themselves, so the sorted
+    order must be a function of the frame alone: three shards, each packing and sorting the
+    same frames in a call of its own, add up to the oracle's histogram (short cutoff with
+    skipping, long cutoff with folds left out)."""
+    monkeypatch.setenv("MDX_RDF_CULL", "1" if cutoff < 10 else "0")
+    monkeypatch.setenv("MDX_RDF_UNFOLD", "1")
+    rng = np.random.default_rng(23)
+    n_per_species, box, frames = [3300, 2100], [40.0, 40.0, 40.0], 4
+    pos = [(rng.random((n, frames, 3)) * 40.0).astype(np.float32) for n in n_per_species]
+    eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+    for rank in range(3):
+        eng.accumulate(pos, shard_rank=rank, shard_count=3)
+    got = eng.read()
+    eng.close()
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
+    np.testing.assert_array_equal(got, ref)
