@@ -72,6 +72,71 @@ FAST_LOOP_MIX = {"packed": 14, "sub_abs": 24, "sqrt": 4, "compare": 4, "min": 4,
 PAIRS_PER_LOOP_ITERATION = 4
 
 
+def _hilbert_rank(q: np.ndarray, bits: int) -> np.ndarray:
+    """Rank of the cells q[:, 0..2] of a 2^bits grid along the three-dimensional Hilbert
+    curve (Skilling's transpose form), as the library's sort kernel orders them."""
+    x = [q[:, 0].astype(np.int64), q[:, 1].astype(np.int64), q[:, 2].astype(np.int64)]
+    top = 1 << (bits - 1)
+    level = top
+    while level > 1:
+        low = level - 1
+        for i in range(3):
+            hit = (x[i] & level) != 0
+            x[0] = np.where(hit, x[0] ^ low, x[0])
+            t = np.where(hit, 0, (x[0] ^ x[i]) & low)
+            x[0] ^= t
+            x[i] ^= t
+        level >>= 1
+    for i in range(1, 3):
+        x[i] ^= x[i - 1]
+    t = np.zeros_like(x[0])
+    level = top
+    while level > 1:
+        t = np.where((x[2] & level) != 0, t ^ (level - 1), t)
+        level >>= 1
+    rank = np.zeros_like(x[0])
+    for j in range(bits - 1, -1, -1):
+        for i in range(3):
+            rank = (rank << 1) | (((x[i] ^ t) >> j) & 1)
+    return rank
+
+
+def fold_free_share(frame: list, box: float) -> dict:
+    """Host estimate, on one frame, of how many minimum-image folds the fast kernel leaves
+    out: the library sorts every species along a Hilbert curve of cells and takes a
+    component of (64 i-atoms, 64 j-atoms) as it is when the two groups' boxes keep every
+    difference within half a box length.  frame: float32 [n, 3] per species, the atoms that
+    take part.  Returns the share of (group pair, component) combinations without a fold
+    (all group pairs of different tiles; the few pairs inside one tile are left out)."""
+    boxes = []
+    for pos in frame:
+        used = len(pos)
+        bits = 1
+        while bits < 4 and (1 << (3 * (bits + 1))) * 8 <= used:
+            bits += 1
+        per_axis = 1 << bits
+        lo = pos.min(axis=0)
+        scale = np.float32(per_axis) / np.float32(box)
+        cell = np.minimum(np.maximum((pos - lo) * scale, 0).astype(np.int64), per_axis - 1)
+        order = np.argsort(_hilbert_rank(cell, bits), kind="stable")
+        pad = -len(pos) % 64
+        sorted_pos = np.concatenate([pos[order], np.full((pad, 3), np.nan, np.float32)])
+        groups = sorted_pos.reshape(-1, 64, 3)
+        boxes.append((np.nanmin(groups, axis=1), np.nanmax(groups, axis=1)))
+    half = np.float32(box) / 2
+    free = total = 0
+    for a in range(len(boxes)):
+        for b in range(a, len(boxes)):
+            (lo_a, hi_a), (lo_b, hi_b) = boxes[a], boxes[b]
+            inside = (hi_b[None] - lo_a[:, None] <= half) & (hi_a[:, None] - lo_b[None] <= half)
+            tile_a = np.arange(len(lo_a)) // 4
+            tile_b = np.arange(len(lo_b)) // 4
+            counted = tile_a[:, None] < tile_b[None] if a == b else np.ones(inside.shape[:2], bool)
+            free += int(inside[counted].sum())
+            total += 3 * int(counted.sum())
+    return {"share": free / total, "group_pairs": total // 3}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,8 +363,23 @@ def main() -> None:
     # measured per-instruction rates, against the kernel time measured in this run
     share = (1.0 / world) if shard_tiles else 1.0
     pairs_per_s_kernel = pairs_per_frame * share * frames_per_launch / (tile_avg_ms * 1e-3)
-    cycles_per_pair = sum(VALU_CYCLES[k] * n for k, n in FAST_LOOP_MIX.items()) \
+    cycles_per_pair_folded = sum(VALU_CYCLES[k] * n for k, n in FAST_LOOP_MIX.items()) \
         / PAIRS_PER_LOOP_ITERATION
+    # sorted frames: a component whose two 64-atom groups lie within half a box of each other
+    # is taken without its two fold instructions; the share is estimated on frame 0
+    unfolded = None
+    if args.kernel == "fast" and os.environ.get("MDX_RDF_UNFOLD") != "0":
+        first = []
+        for s_idx, n in enumerate(n_per_species):
+            idx = (np.arange(1, n, dtype=np.uint64)[:, None] * np.uint64(n_frames * 3)
+                   + np.arange(3, dtype=np.uint64)[None, :])   # strict masks: atom 0 left out
+            first.append(engine.uniform_fill_at(idx, 1000 + s_idx + seed_shift, 0.0, box)
+                         .reshape(n - 1, 3))
+        group_edge = min(box * (64.0 / (n - 1)) ** (1 / 3) for n in n_per_species)
+        if group_edge < 0.3 * box and max(n_per_species) > 7 * 256:
+            unfolded = fold_free_share(first, box)
+    cycles_per_pair = cycles_per_pair_folded - \
+        (6 * VALU_CYCLES["sub_abs"] * unfolded["share"] if unfolded else 0.0)
     issue_bound = 1024 * 2.4e9 * 64 / cycles_per_pair
     valu = {
         "pairs_per_s_kernel": pairs_per_s_kernel,
@@ -312,6 +392,8 @@ def main() -> None:
             "model": "instruction mix of the hot loop x sustained cycles per wave64 "
                      "instruction per SIMD (profiles/r02_valu_probe.txt), 1024 SIMDs, 2.4 GHz",
             "valu_cycles_per_pair_model": cycles_per_pair,
+            "valu_cycles_per_pair_every_component_folded": cycles_per_pair_folded,
+            "fold_free_components": unfolded,
             "issue_bound_pairs_per_s": issue_bound,
             "frac_of_issue_bound": pairs_per_s_kernel / issue_bound,
         })

@@ -189,17 +189,23 @@ __host__ __device__ inline int curve_offset(int cell_bits) {
 // (+inf, -inf), which is out of everybody's reach.
 // The sorted order is a function of the frame alone (within a cell: the order of the
 // input), never of the timing of the block's threads: ranks that share the tile pairs of
-// a frame sort it each for themselves, and their tiles must hold the same atoms.  So the
-// four waves take a quarter of the atoms each, in input order, with a table of cell
-// counts per wave: counts first (LDS atomics, whose order does not matter), then every
-// wave's first position per cell (cells in curve order, within a cell wave by wave),
-// then the placement, 64 atoms at a time -- the lanes that share a cell are found with
-// ballots, lowest lane first, and take consecutive positions.
+// a frame sort it each for themselves, and their tiles must hold the same atoms.  Counts
+// come from LDS atomics (whose order does not matter), the cells' first positions from a
+// scan in curve order.  Placement, usual case (a species of at most kSortIndexed atoms, no
+// cell above kSortCellMax): the atoms' indices are scattered into an LDS list with atomics,
+// in whatever order, every cell's piece of the list is then sorted by index (one thread
+// per cell, insertion sort of about ten entries), and the coordinates are gathered along
+// the list.  Otherwise (large species, clustered atoms): the four waves take a quarter of
+// the atoms each, in input order, with a table of cell counts per wave, and place 64
+// atoms at a time -- the lanes that share a cell are found with ballots, lowest lane
+// first, and take consecutive positions.  Both give the same order.
 // frame_lo holds the frame's smallest coordinate per component (the frame is compact:
 // every coordinate lies within one box length above it), so the cell grid follows a
 // trajectory that is not wrapped into [0, L).  Frames that are not compact are copied
 // unsorted (they go to the table kernel, which skips nothing); their boxes are never read.
-// Dynamic LDS: uint32 [5][n_cells].
+// Dynamic LDS: uint32 [5][n_cells] | uint16 list[used] (species of at most kSortIndexed).
+constexpr int kSortIndexed = 12288;
+constexpr uint32_t kSortCellMax = 64;
 __global__ __launch_bounds__(256) void rdf_sort_kernel(
     const float *__restrict__ packed, float *__restrict__ sorted, int64_t n_pad, int n_tiles,
     const SortSpecies *__restrict__ species, const int32_t *__restrict__ frame_wrapped,
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
     float *__restrict__ boxes) {
   extern __shared__ __align__(16) uint32_t sort_lds[];
   __shared__ uint32_t wave_total[4];
+  __shared__ uint32_t largest_cell;
   const SortSpecies sp = species[blockIdx.x];
   const int f = blockIdx.y;
   const int tid = threadIdx.x;
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   uint32_t *cell_count = sort_lds;                        // all atoms of a cell
   uint32_t *own = sort_lds + (1 + wave) * n_cells;        // this wave's atoms of a cell
   for (int i = tid; i < 5 * n_cells; i += 256) sort_lds[i] = 0u;
+  if (tid == 0) largest_cell = 0u;
   __syncthreads();
   const uint16_t *rank_of_cell = curve + curve_offset(sp.cell_bits);
   float lo[3], scale[3];
@@ -253,14 +261,16 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   {
     const int per_thread = (n_cells + 255) / 256;
     const int c0 = tid * per_thread;
-    uint32_t sum = 0;
+    uint32_t sum = 0, largest = 0;
     for (int k = 0; k < per_thread; ++k)
       if (c0 + k < n_cells) {
         uint32_t n = 0;
         for (int w = 0; w < 4; ++w) n += sort_lds[(1 + w) * n_cells + c0 + k];
         cell_count[c0 + k] = n;
         sum += n;
+        largest = max(largest, n);
       }
+    atomicMax(&largest_cell, largest);
     uint32_t incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t below = __shfl_up(incl, off);
@@ -280,6 +290,30 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       }
   }
   __syncthreads();
+  if (sp.used <= kSortIndexed && largest_cell <= kSortCellMax) {
+    uint16_t *list = reinterpret_cast<uint16_t *>(sort_lds + 5 * n_cells);
+    const uint32_t *cell_first = sort_lds + n_cells;  // wave 0's first position = the cell's
+    for (int c = tid; c < n_cells; c += 256) cell_count[c] = cell_first[c];
+    __syncthreads();
+    for (int i = tid; i < sp.used; i += 256)
+      list[atomicAdd(&cell_count[cell_of(i)], 1u)] = static_cast<uint16_t>(i);
+    __syncthreads();
+    for (int c = tid; c < n_cells; c += 256) {
+      const int first = static_cast<int>(cell_first[c]), last = static_cast<int>(cell_count[c]);
+      for (int a = first + 1; a < last; ++a) {
+        const uint16_t v = list[a];
+        int b = a;
+        for (; b > first && list[b - 1] > v; --b) list[b] = list[b - 1];
+        list[b] = v;
+      }
+    }
+    __syncthreads();
+    for (int pos = tid; pos < sp.used; pos += 256) {
+      const int i = list[pos];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Y[c * n_pad + pos] = X[c * n_pad + i];
+    }
+  } else
   for (int i0 = w_begin; i0 < w_end; i0 += 64) {
     const int i = i0 + lane;
     const bool valid = i < w_end;
@@ -289,6 +323,9 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
     const uint32_t start = valid ? own[cell] : 0u;
     uint32_t dst = 0u;
     unsigned long long remaining = __ballot(valid);
+#ifdef MDX_TIMING_SWITCHES
+    if (p.timing_mask >= 100) { remaining = 0ull; dst = i; }
+#endif
     while (remaining != 0ull) {
       const int leader = __builtin_ctzll(remaining);
       const uint32_t c0 = static_cast<uint32_t>(
@@ -309,6 +346,9 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   const float nan = __builtin_nanf("");
   for (int i = sp.used + tid; i < slots; i += 256)
     for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
+#ifdef MDX_TIMING_SWITCHES
+  if (p.timing_mask >= 101) return;
+#endif
   __syncthreads();  // the block reads back what it wrote
   // bounding boxes: wave w takes quarter w of every tile (lane = slot); NaN padding is
   // ignored by fminf / fmaxf
@@ -801,7 +841,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
     const float *jbox = jboxes + 6 * q;
     if (!kDiag && p.cull_on && box_gap2(ibox, jbox, p) > p.cull_gap2) continue;
 #ifdef MDX_TIMING_SWITCHES
-    const int mask = p.timing_mask >= 0 ? p.timing_mask : fold_mask(ibox, jbox, hx, hy, hz);
+    const int mask = (p.timing_mask >= 0 && p.timing_mask < 8) ? p.timing_mask : (p.timing_mask >= 100 ? 7 : fold_mask(ibox, jbox, hx, hy, hz));
 #else
     const int mask = fold_mask(ibox, jbox, hx, hy, hz);
 #endif
@@ -1735,8 +1775,10 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
     p.cull_on = (h->sort_frames && worth) ? 1 : 0;
     if (h->sort_frames) sort_table = table;  // uploaded with the other device tables below
     for (const SortSpecies &sp : sort_table)
-      h->sort_lds_bytes =
-          std::max(h->sort_lds_bytes, sizeof(uint32_t) * 5 * (size_t(1) << (3 * sp.cell_bits)));
+      h->sort_lds_bytes = std::max(
+          h->sort_lds_bytes,
+          sizeof(uint32_t) * 5 * (size_t(1) << (3 * sp.cell_bits)) +
+              (sp.used <= kSortIndexed ? sizeof(uint16_t) * static_cast<size_t>(sp.used) : 0) + 16);
     if (h->sort_lds_bytes > 0)
       MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_sort_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,

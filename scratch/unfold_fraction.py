@@ -78,3 +78,11 @@ for i in range(0, len(pa), 7):
         r = np.abs(pb[j][None, :, :] - pa[i][:, None, :])
         cnt += (r.max(axis=(0, 1)) <= L / 2).sum(); tot += 3
 print("brute force unfolded fraction %.3f" % (cnt / tot))
+
+# components whose differences all lie beyond half a box (one image shift for the whole group pair)
+la, ha = groups(a, L, 3, "hilbert"); lb, hb = groups(b, L, 3, "hilbert")
+h = L / 2
+up = (lb[None] - ha[:, None] > h)      # every x_j - x_i above h
+down = (la[:, None] - hb[None] > h)    # every x_i - x_j above h
+inside = (hb[None] - la[:, None] <= h) & (ha[:, None] - lb[None] <= h)
+print("inside %.3f shifted %.3f" % (inside.mean(), (up | down).mean()))
