@@ -621,11 +621,11 @@ __device__ __forceinline__ uint32_t fast_position_bits(float xi, float yi, float
 
 // Literal squared distance of a pair in a wrapped frame (see table_tile_loop).
 __device__ __forceinline__ float literal_wrapped_s(float xi, float yi, float zi, float xj,
-                                                   float yj, float zj, const RdfParams &p) {
+                                                   float yj, float zj, const float box[3]) {
   const float rx = xj - xi, ry = yj - yi, rz = zj - zi;
-  const float ax = fminf(fabsf(rx), p.box[0] - fabsf(rx));
-  const float ay = fminf(fabsf(ry), p.box[1] - fabsf(ry));
-  const float az = fminf(fabsf(rz), p.box[2] - fabsf(rz));
+  const float ax = fminf(fabsf(rx), box[0] - fabsf(rx));
+  const float ay = fminf(fabsf(ry), box[1] - fabsf(ry));
+  const float az = fminf(fabsf(rz), box[2] - fabsf(rz));
   return (ax * ax + ay * ay) + az * az;
 }
 
@@ -659,6 +659,19 @@ __device__ __forceinline__ void lds_count(uint32_t byte_offset, uint32_t value) 
   asm volatile("ds_add_u32 %0, %1" : : "v"(byte_offset), "v"(value) : "memory");
 }
 
+// Wave-uniform values that the fast kernel keeps in vector registers: the scalar file is
+// the scarce one there (eight waves per SIMD), and what the resolving pass reads is used
+// lane by lane anyway.
+struct FastRegs {
+  float box[3];
+  float s_cut;
+  uint32_t keep_bits;
+  uint32_t frac_bits;
+  int last_bin;     // nbins - 1
+  uint32_t shift;   // frac_bits - 2: position bits -> byte offset of the bin's LDS word
+  uint32_t dump;    // the lane's dump position (nbins + 1 + lane, every fraction bit set)
+};
+
 constexpr int kQueueSlots = 8;  // near-edge pairs a lane can note before they are resolved
 constexpr int kQueueBytes = 2 * kQueueSlots;  // per lane: 16-bit entries
 
@@ -669,7 +682,7 @@ __device__ __forceinline__ void fast_resolve_queue(
     int &count, uint16_t *__restrict__ queue, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
     float hx, float hy, float hz, float scale, float magic, uint32_t *__restrict__ hist,
-    const float *__restrict__ g_thr, const RdfParams &p) {
+    const float *__restrict__ g_thr, const FastRegs &r) {
   while (__any(count > 0)) {
     if (count > 0) {
       --count;
@@ -678,15 +691,15 @@ __device__ __forceinline__ void fast_resolve_queue(
       const float pxj = xj[j], pyj = yj[j], pzj = zj[j];
       const uint32_t bits =
           fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic, entry >> 8);
-      const bool counted = bits < p.fast_keep_bits;
-      const int guess = static_cast<int>((bits & 0x7FFFFFu) >> p.fast_frac_bits);
-      const float s = literal_wrapped_s(xi, yi, zi, pxj, pyj, pzj, p);
-      int e = min(max(guess, 0), p.nbins - 1);
+      const bool counted = bits < r.keep_bits;
+      const int guess = static_cast<int>((bits & 0x7FFFFFu) >> r.frac_bits);
+      const float s = literal_wrapped_s(xi, yi, zi, pxj, pyj, pzj, r.box);
+      int e = min(max(guess, 0), r.last_bin);
       const float lo = g_thr[e];
       const float hi = g_thr[e + 1];
       e += (s >= hi) ? 1 : 0;
       e -= (s < lo) ? 1 : 0;
-      const bool kept = s < p.s_cut;
+      const bool kept = s < r.s_cut;
       if (counted && !(kept && e == guess)) atomicSub(&hist[guess], 1u);
       if (kept && !(counted && e == guess)) atomicAdd(&hist[e], 1u);
     }
@@ -695,25 +708,25 @@ __device__ __forceinline__ void fast_resolve_queue(
 
 // The j-atoms [j_begin, j_end) of one (tile pair, frame) item: lane = i-atom.  Near-edge
 // pairs are noted in the lane's queue (`count` entries so far) for the caller to resolve.
+// The loop reads one iteration ahead: on entry nx, ny, nz hold the atoms j_begin .. j_begin
+// + 3, on exit the atoms j_end .. j_end + 3 when j_end < j_limit (the caller's next range
+// then starts without waiting for a load).
 template <bool kDiag, int kFold = 7>
 __device__ __forceinline__ void fast_j_range(
-    int j_begin, int j_end, int &count, float xi, float yi, float zi,
+    int j_begin, int j_end, int j_limit, float4 &nx, float4 &ny, float4 &nz, int &count,
+    float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
     uint32_t *__restrict__ hist, uint16_t *__restrict__ queue, const float *__restrict__ g_thr,
-    const RdfParams &p, int tid, float hx, float hy, float hz, float scale, float magic,
+    const RdfParams &p, const FastRegs &r, int tid, float hx, float hy, float hz, float scale, float magic,
     uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
-  const uint32_t shift = in_vgpr(p.fast_frac_bits - 2u);
+  const uint32_t shift = r.shift;
   const uint32_t edge = p.fast_edge_units;
-  // position nbins + 1 + lane: 64 distinct words, so the lanes of a wave never collide there
-  const uint32_t dump = p.fast_dump_bits + (static_cast<uint32_t>(tid & 63) << p.fast_frac_bits);
+  const uint32_t dump = r.dump;
   const v2f xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
   const v2f scale2 = {scale, scale}, magic2 = {magic, magic};
-  float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
-  float4 ny = *reinterpret_cast<const float4 *>(yj + j_begin);
-  float4 nz = *reinterpret_cast<const float4 *>(zj + j_begin);
   for (int j0 = j_begin; j0 < j_end; j0 += 4) {
     const float4 cx = nx, cy = ny, cz = nz;
-    const int jn = (j0 + 4 < j_end) ? j0 + 4 : j0;
+    const int jn = (j0 + 4 < j_limit) ? j0 + 4 : j0;
     nx = *reinterpret_cast<const float4 *>(xj + jn);
     ny = *reinterpret_cast<const float4 *>(yj + jn);
     nz = *reinterpret_cast<const float4 *>(zj + jn);
@@ -773,7 +786,7 @@ __device__ __forceinline__ void fast_j_range(
       // a lane has room for four more pairs or everything is resolved now
       if (__any(count > kQueueSlots - 4))
         fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
-                           hist, g_thr, p);
+                           hist, g_thr, r);
     }
   }
 }
@@ -783,38 +796,51 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one) {
   const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
   const int j_end = (j_count + 3) & ~3;  // padding slots hold NaN and are never counted
   if (j_begin >= j_end) return;
   int count = 0;
-  fast_j_range<kDiag>(j_begin, j_end, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid,
-                      hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+  float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
+  float4 ny = *reinterpret_cast<const float4 *>(yj + j_begin);
+  float4 nz = *reinterpret_cast<const float4 *>(zj + j_begin);
+  fast_j_range<kDiag>(j_begin, j_end, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist,
+                      queue, g_thr, p, r, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
   fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
-                     g_thr, p);
+                     g_thr, r);
 }
 
-// Which components of the pairs (64 i-atoms in ibox, 64 j-atoms in jbox) need the
-// minimum-image fold: bit c is clear when every difference x_j - x_i of component c lies
-// within [-L_c/2, L_c/2].  The boxes are the exact extremes of the float32 coordinates and
-// float32 subtraction is monotone, so fl(x_j - x_i) <= fl(jhi - ilo) <= L_c/2 (and likewise
-// the other way round): the literal rule then rounds r / L_c to zero and keeps r itself, and
-// so does the loop variant without the fold -- for such a component it is not an
-// approximation at all.  An empty box is (+inf, -inf); its differences are -inf (or NaN,
-// which compares false and asks for the fold), and its atoms are NaN padding either way.
-__device__ __forceinline__ int fold_mask(const float *__restrict__ ibox,
-                                         const float *__restrict__ jbox, float hx, float hy,
-                                         float hz) {
-  const float h[3] = {hx, hy, hz};
-  int mask = 0;
+// Which components of the pairs (64 i-atoms in ibox, 64 j-atoms of a quarter of the j-tile)
+// need the minimum-image fold, for the four quarters at once: bits [3q, 3q + 3) of the
+// result belong to quarter q, and bit c of them is clear when every difference x_j - x_i of
+// component c lies within [-L_c/2, L_c/2].  The boxes are the exact extremes of the float32
+// coordinates and float32 subtraction is monotone, so fl(x_j - x_i) <= fl(jhi - ilo) <=
+// L_c/2 (and likewise the other way round): the literal rule then rounds r / L_c to zero
+// and keeps r itself, and so does the loop variant without the fold -- for such a
+// component it is not an approximation at all.  An empty box is (+inf, -inf); its
+// differences are -inf (or NaN, which compares false and asks for the fold), and its atoms
+// are NaN padding either way.  The 24 conditions (quarter, side, component) are evaluated
+// by the first 24 lanes of the wave, one each, and collected with a ballot.
+__device__ __forceinline__ uint32_t fold_masks(const float *__restrict__ ibox,
+                                               const float *__restrict__ jboxes, int lane,
+                                               float hx, float hy, float hz) {
+  const int l = lane < 24 ? lane : 0;
+  const int q = l / 6, r = l - 6 * q;
+  const int side = r >= 3 ? 1 : 0, c = r - 3 * side;
+  const float *jbox = jboxes + 6 * q;
+  // side 0: highest x_j - lowest x_i; side 1: highest x_i - lowest x_j
+  const float high = side ? ibox[3 + c] : jbox[3 + c];
+  const float low = side ? jbox[c] : ibox[c];
+  const float h = c == 0 ? hx : c == 1 ? hy : hz;
+  const unsigned long long ok = __ballot(lane < 24 && high - low <= h);
+  const uint32_t bits = static_cast<uint32_t>(ok);
+  const uint32_t inside = bits & (bits >> 3);  // bits 6q + c: both sides hold
+  uint32_t masks = 0u;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const bool inside = (jbox[3 + c] - ibox[c] <= h[c]) && (ibox[3 + c] - jbox[c] <= h[c]);
-    mask |= inside ? 0 : (1 << c);
-  }
-  return __builtin_amdgcn_readfirstlane(mask);
+  for (int k = 0; k < 4; ++k) masks |= (~(inside >> (6 * k)) & 7u) << (3 * k);
+  return masks;
 }
 
 // One (tile pair, frame) item of a sorted frame: the wave's 64 i-atoms and each quarter of
@@ -827,13 +853,16 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop_sorted(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one, const float *__restrict__ ibox,
     const float *__restrict__ jboxes) {
   const int j_end = (j_count + 3) & ~3;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int count = 0;
+  float4 nx, ny, nz;
+  int ahead = -1;  // the j-atom that nx, ny, nz start at
+  const uint32_t masks = fold_masks(ibox, jboxes, tid & 63, hx, hy, hz);
   for (int q = kDiag ? wave : 0; q < kTile / 64; ++q) {
     const int lo = 64 * q;
     if (lo >= j_end) break;
@@ -841,23 +870,31 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
     const float *jbox = jboxes + 6 * q;
     if (!kDiag && p.cull_on && box_gap2(ibox, jbox, p) > p.cull_gap2) continue;
 #ifdef MDX_TIMING_SWITCHES
-    const int mask = (p.timing_mask >= 0 && p.timing_mask < 8) ? p.timing_mask : (p.timing_mask >= 100 ? 7 : fold_mask(ibox, jbox, hx, hy, hz));
+    const int mask = (p.timing_mask >= 0 && p.timing_mask < 8)
+                         ? p.timing_mask
+                         : (p.timing_mask >= 100 ? 7 : static_cast<int>((masks >> (3 * q)) & 7u));
 #else
-    const int mask = fold_mask(ibox, jbox, hx, hy, hz);
+    const int mask = static_cast<int>((masks >> (3 * q)) & 7u);
 #endif
+    if (ahead != lo) {
+      nx = *reinterpret_cast<const float4 *>(xj + lo);
+      ny = *reinterpret_cast<const float4 *>(yj + lo);
+      nz = *reinterpret_cast<const float4 *>(zj + lo);
+    }
+    ahead = hi;
     if (kDiag && q == wave) {
       // the wave's own quarter: one box on both sides, as a rule narrower than half the box
       if (mask == 0)
-        fast_j_range<true, 0>(lo, hi, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid,
+        fast_j_range<true, 0>(lo, hi, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       else
-        fast_j_range<true, 7>(lo, hi, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid,
+        fast_j_range<true, 7>(lo, hi, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       continue;
     }
 #define MDX_FOLD_CASE(M)                                                                     \
   case M:                                                                                    \
-    fast_j_range<false, M>(lo, hi, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, tid, \
+    fast_j_range<false, M>(lo, hi, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid, \
                            hx, hy, hz, scale, magic, addr_mask, frac_mask, one);            \
     break;
     switch (mask) {
@@ -873,7 +910,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
 #undef MDX_FOLD_CASE
   }
   fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
-                     g_thr, p);
+                     g_thr, r);
 }
 
 // Persistent blocks with shared work counters.  A chunk is up to frames_per_chunk
@@ -920,6 +957,15 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const uint32_t addr_mask = in_vgpr(p.fast_addr_mask);
   const uint32_t frac_mask = in_vgpr(p.fast_frac_mask);
   const uint32_t one = in_vgpr(1u);
+  FastRegs r;
+  for (int c = 0; c < 3; ++c) r.box[c] = in_vgpr(p.box[c]);
+  r.s_cut = in_vgpr(p.s_cut);
+  r.keep_bits = in_vgpr(p.fast_keep_bits);
+  r.frac_bits = in_vgpr(p.fast_frac_bits);
+  r.last_bin = static_cast<int>(in_vgpr(static_cast<uint32_t>(p.nbins - 1)));
+  r.shift = in_vgpr(p.fast_frac_bits - 2u);
+  // position nbins + 1 + lane: 64 distinct words, so the lanes of a wave never collide there
+  r.dump = p.fast_dump_bits + (static_cast<uint32_t>(tid & 63) << p.fast_frac_bits);
 
   // Adds the block's LDS counts of `key` to the device histogram and clears them.
   auto flush = [&](int key) {
@@ -995,18 +1041,18 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
           const float *ibox = quarters + (tp.tile_i * 4 + wave) * 6;
           const float *jboxes = quarters + tp.tile_j * 4 * 6;
           if (tp.diagonal)
-            fast_tile_loop_sorted<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p,
+            fast_tile_loop_sorted<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, r,
                                         tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one,
                                         ibox, jboxes);
           else
             fast_tile_loop_sorted<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr,
-                                         p, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask,
-                                         one, ibox, jboxes);
+                                         p, r, tid, hx, hy, hz, scale, magic, addr_mask,
+                                         frac_mask, one, ibox, jboxes);
         } else if (tp.diagonal)
-          fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+          fast_tile_loop<true>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, r, tid,
                                hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
         else
-          fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, tid,
+          fast_tile_loop<false>(xi, yi, zi, xj, yj, zj, tp.j_count, hist, queue, g_thr, p, r, tid,
                                 hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       }
       __syncthreads();  // the chunk's counts are in before a flush or the next claim
