@@ -197,8 +197,9 @@ __host__ __device__ inline int curve_offset(int cell_bits) {
 // per cell, insertion sort of about ten entries), and the coordinates are gathered along
 // the list.  Otherwise (large species, clustered atoms): the four waves take a quarter of
 // the atoms each, in input order, with a table of cell counts per wave, and place 64
-// atoms at a time -- the lanes that share a cell are found with ballots, lowest lane
-// first, and take consecutive positions.  Both give the same order.
+// atoms at a time with one LDS atomic each -- a lane alone in its cell has its position;
+// lanes that share a cell are found with ballots and take the cell's positions lowest lane
+// first.  Both give the same order.
 // frame_lo holds the frame's smallest coordinate per component (the frame is compact:
 // every coordinate lies within one box length above it), so the cell grid follows a
 // trajectory that is not wrapped into [0, L).  Frames that are not compact are copied
@@ -318,11 +319,18 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
     const int i = i0 + lane;
     const bool valid = i < w_end;
     const uint32_t cell = valid ? cell_of(i) : 0xFFFFFFFFu;
-    // the wave's next free position in the lane's cell (the wave's LDS operations keep
-    // their order, so the previous group's updates are in)
-    const uint32_t start = valid ? own[cell] : 0u;
-    uint32_t dst = 0u;
-    unsigned long long remaining = __ballot(valid);
+    // The wave's next free position in the lane's cell, before and after the group has
+    // taken its places there (the wave's LDS operations keep their order).  A lane alone in
+    // its cell -- the rule, with thousands of cells -- owns the one place; lanes that share
+    // a cell are ranked by lane with ballots, lowest first.
+    uint32_t first = 0u, taken = 0u;
+    if (valid) {
+      first = own[cell];
+      atomicAdd(&own[cell], 1u);
+      taken = own[cell] - first;
+    }
+    uint32_t dst = first;
+    unsigned long long remaining = __ballot(taken > 1u);
 #ifdef MDX_TIMING_SWITCHES
     if (p.timing_mask >= 100) { remaining = 0ull; dst = i; }
 #endif
@@ -330,12 +338,8 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       const int leader = __builtin_ctzll(remaining);
       const uint32_t c0 = static_cast<uint32_t>(
           __builtin_amdgcn_readlane(static_cast<int>(cell), leader));
-      const uint32_t first = static_cast<uint32_t>(
-          __builtin_amdgcn_readlane(static_cast<int>(start), leader));
       const unsigned long long same = __ballot(cell == c0);
-      if (cell == c0)
-        dst = first + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
-      if (lane == leader) own[c0] = first + static_cast<uint32_t>(__popcll(same));
+      if (cell == c0) dst = first + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
       remaining &= ~same;
     }
     if (valid) {
@@ -673,24 +677,25 @@ struct FastRegs {
 };
 
 constexpr int kQueueSlots = 8;  // near-edge pairs a lane can note before they are resolved
-constexpr int kQueueBytes = 2 * kQueueSlots;  // per lane: 16-bit entries
+constexpr int kQueueBytes = kQueueSlots;  // per lane: one byte per entry, the j-atom
 
 // Resolves the noted pairs of every lane: the hot loop has already counted them in the
 // bin of the approximate position (if that was below the cutoff); here the literal
 // squared distance decides, and the count is moved when the two disagree.
 __device__ __forceinline__ void fast_resolve_queue(
-    int &count, uint16_t *__restrict__ queue, float xi, float yi, float zi,
+    int &count, uint8_t *__restrict__ queue, uint32_t masks, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
     float hx, float hy, float hz, float scale, float magic, uint32_t *__restrict__ hist,
     const float *__restrict__ g_thr, const FastRegs &r) {
   while (__any(count > 0)) {
     if (count > 0) {
       --count;
-      const int entry = queue[count];  // j-atom | components the hot loop folded << 8
-      const int j = entry & 255;
+      const int j = queue[count];
       const float pxj = xj[j], pyj = yj[j], pzj = zj[j];
+      // the components the hot loop folded for this j-atom's quarter of the tile
+      const int fold = static_cast<int>((masks >> (3 * (j >> 6))) & 7u);
       const uint32_t bits =
-          fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic, entry >> 8);
+          fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic, fold);
       const bool counted = bits < r.keep_bits;
       const int guess = static_cast<int>((bits & 0x7FFFFFu) >> r.frac_bits);
       const float s = literal_wrapped_s(xi, yi, zi, pxj, pyj, pzj, r.box);
@@ -710,13 +715,15 @@ __device__ __forceinline__ void fast_resolve_queue(
 // pairs are noted in the lane's queue (`count` entries so far) for the caller to resolve.
 // The loop reads one iteration ahead: on entry nx, ny, nz hold the atoms j_begin .. j_begin
 // + 3, on exit the atoms j_end .. j_end + 3 when j_end < j_limit (the caller's next range
-// then starts without waiting for a load).
+// then starts without waiting for a load).  kFold: the components this range folds; masks:
+// the same for every quarter of the tile (three bits each), which the resolving pass needs
+// to repeat the loop's arithmetic for a noted pair.
 template <bool kDiag, int kFold = 7>
 __device__ __forceinline__ void fast_j_range(
     int j_begin, int j_end, int j_limit, float4 &nx, float4 &ny, float4 &nz, int &count,
-    float xi, float yi, float zi,
+    uint32_t masks, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
-    uint32_t *__restrict__ hist, uint16_t *__restrict__ queue, const float *__restrict__ g_thr,
+    uint32_t *__restrict__ hist, uint8_t *__restrict__ queue, const float *__restrict__ g_thr,
     const RdfParams &p, const FastRegs &r, int tid, float hx, float hy, float hz, float scale, float magic,
     uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
   const uint32_t shift = r.shift;
@@ -779,13 +786,13 @@ __device__ __forceinline__ void fast_j_range(
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (near[u]) {
-          queue[count] = static_cast<uint16_t>((j0 + u) | (kFold << 8));
+          queue[count] = static_cast<uint8_t>(j0 + u);
           ++count;
         }
       }
       // a lane has room for four more pairs or everything is resolved now
       if (__any(count > kQueueSlots - 4))
-        fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
+        fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
                            hist, g_thr, r);
     }
   }
@@ -796,7 +803,7 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
+    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one) {
   const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
@@ -806,9 +813,11 @@ __device__ __forceinline__ void fast_tile_loop(
   float4 nx = *reinterpret_cast<const float4 *>(xj + j_begin);
   float4 ny = *reinterpret_cast<const float4 *>(yj + j_begin);
   float4 nz = *reinterpret_cast<const float4 *>(zj + j_begin);
-  fast_j_range<kDiag>(j_begin, j_end, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist,
-                      queue, g_thr, p, r, tid, hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
-  fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
+  const uint32_t masks = 0xFFFu;  // every component folded
+  fast_j_range<kDiag>(j_begin, j_end, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj,
+                      hist, queue, g_thr, p, r, tid, hx, hy, hz, scale, magic, addr_mask,
+                      frac_mask, one);
+  fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
                      g_thr, r);
 }
 
@@ -853,7 +862,7 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop_sorted(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
+    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one, const float *__restrict__ ibox,
     const float *__restrict__ jboxes) {
@@ -862,7 +871,9 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
   int count = 0;
   float4 nx, ny, nz;
   int ahead = -1;  // the j-atom that nx, ny, nz start at
-  const uint32_t masks = fold_masks(ibox, jboxes, tid & 63, hx, hy, hz);
+  uint32_t masks = fold_masks(ibox, jboxes, tid & 63, hx, hy, hz);
+  // the wave's own quarter of a diagonal tile has two variants only: all or nothing
+  if (kDiag && ((masks >> (3 * wave)) & 7u) != 0u) masks |= 7u << (3 * wave);
   for (int q = kDiag ? wave : 0; q < kTile / 64; ++q) {
     const int lo = 64 * q;
     if (lo >= j_end) break;
@@ -885,16 +896,16 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
     if (kDiag && q == wave) {
       // the wave's own quarter: one box on both sides, as a rule narrower than half the box
       if (mask == 0)
-        fast_j_range<true, 0>(lo, hi, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
+        fast_j_range<true, 0>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       else
-        fast_j_range<true, 7>(lo, hi, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
+        fast_j_range<true, 7>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
                               hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
       continue;
     }
 #define MDX_FOLD_CASE(M)                                                                     \
   case M:                                                                                    \
-    fast_j_range<false, M>(lo, hi, j_end, nx, ny, nz, count, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid, \
+    fast_j_range<false, M>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid, \
                            hx, hy, hz, scale, magic, addr_mask, frac_mask, one);            \
     break;
     switch (mask) {
@@ -909,7 +920,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
     }
 #undef MDX_FOLD_CASE
   }
-  fast_resolve_queue(count, queue, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
+  fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
                      g_thr, r);
 }
 
@@ -926,7 +937,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
 // pace.  Frames that are not "compact" are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] (bins, the overflow bin, kDumpWords dump words) |
-// uint16 queue[kTile][kQueueSlots] | uint32 claim.
+// uint8 queue[kTile][kQueueSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
 // The loop needs every wave a SIMD can hold to hide its dependent chains (sub, sub, mul,
@@ -944,8 +955,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   const int tid = threadIdx.x;
-  uint16_t *queue = reinterpret_cast<uint16_t *>(
-      lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueBytes);
+  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueBytes;
   uint32_t *claim = reinterpret_cast<uint32_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words) +
                                                  static_cast<size_t>(kTile) * kQueueBytes);
 
