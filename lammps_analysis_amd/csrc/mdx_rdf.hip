@@ -291,6 +291,30 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       }
   }
   __syncthreads();
+  const int first_tile = sp.first_slot / kTile;
+  float *frame_boxes = boxes + static_cast<int64_t>(f) * 5 * n_tiles * 6;
+  float *quarter_boxes = frame_boxes + static_cast<int64_t>(n_tiles) * 6;
+  const float nan = __builtin_nanf("");
+  // the box of the 64 slots a wave holds (NaN padding is ignored by fminf / fmaxf)
+  auto quarter_box = [&](int tile, const float v[3]) {
+    float mn[3], mx[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = fminf(__builtin_inff(), v[c]);
+      mx[c] = fmaxf(-__builtin_inff(), v[c]);
+      for (int off = 32; off > 0; off >>= 1) {
+        mn[c] = fminf(mn[c], __shfl_xor(mn[c], off));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off));
+      }
+    }
+    if (lane == 0) {
+      float *b = quarter_boxes + (static_cast<int64_t>(first_tile + tile) * 4 + wave) * 6;
+      for (int c = 0; c < 3; ++c) {
+        b[c] = mn[c];
+        b[3 + c] = mx[c];
+      }
+    }
+  };
   if (sp.used <= kSortIndexed && largest_cell <= kSortCellMax) {
     uint16_t *list = reinterpret_cast<uint16_t *>(sort_lds + 5 * n_cells);
     const uint32_t *cell_first = sort_lds + n_cells;  // wave 0's first position = the cell's
@@ -309,12 +333,21 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       }
     }
     __syncthreads();
-    for (int pos = tid; pos < sp.used; pos += 256) {
-      const int i = list[pos];
+    // gather along the list, tile by tile: wave w writes quarter w (padding included) and
+    // takes its box from the values in hand
+    for (int t = 0; t < sp.tiles; ++t) {
+      const int pos = t * kTile + tid;
+      float v[3] = {nan, nan, nan};
+      if (pos < sp.used) {
+        const int i = list[pos];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Y[c * n_pad + pos] = X[c * n_pad + i];
+        for (int c = 0; c < 3; ++c) v[c] = X[c * n_pad + i];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Y[c * n_pad + pos] = v[c];
+      quarter_box(t, v);
     }
-  } else
+  } else {
   for (int i0 = w_begin; i0 < w_end; i0 += 64) {
     const int i = i0 + lane;
     const bool valid = i < w_end;
@@ -347,36 +380,17 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       for (int c = 0; c < 3; ++c) Y[c * n_pad + dst] = X[c * n_pad + i];
     }
   }
-  const float nan = __builtin_nanf("");
   for (int i = sp.used + tid; i < slots; i += 256)
     for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
 #ifdef MDX_TIMING_SWITCHES
   if (p.timing_mask >= 101) return;
 #endif
   __syncthreads();  // the block reads back what it wrote
-  // bounding boxes: wave w takes quarter w of every tile (lane = slot); NaN padding is
-  // ignored by fminf / fmaxf
-  const int first_tile = sp.first_slot / kTile;
-  float *frame_boxes = boxes + static_cast<int64_t>(f) * 5 * n_tiles * 6;
-  float *quarter_boxes = frame_boxes + static_cast<int64_t>(n_tiles) * 6;
   for (int t = 0; t < sp.tiles; ++t) {
-    float mn[3], mx[3];
-    for (int c = 0; c < 3; ++c) {
-      const float v = Y[c * n_pad + t * kTile + tid];
-      mn[c] = fminf(__builtin_inff(), v);
-      mx[c] = fmaxf(-__builtin_inff(), v);
-      for (int off = 32; off > 0; off >>= 1) {
-        mn[c] = fminf(mn[c], __shfl_xor(mn[c], off));
-        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], off));
-      }
-    }
-    if ((tid & 63) == 0) {
-      float *b = quarter_boxes + (static_cast<int64_t>(first_tile + t) * 4 + (tid >> 6)) * 6;
-      for (int c = 0; c < 3; ++c) {
-        b[c] = mn[c];
-        b[3 + c] = mx[c];
-      }
-    }
+    float v[3];
+    for (int c = 0; c < 3; ++c) v[c] = Y[c * n_pad + t * kTile + tid];
+    quarter_box(t, v);
+  }
   }
   __syncthreads();
   for (int t = tid; t < sp.tiles; t += 256) {
