@@ -16,13 +16,16 @@
 //        rdf_tile_kernel  : one block per (tile pair, frame group); the literal
 //          kernel, the table kernel for frames the fast kernel leaves out.
 //
-// Short cutoffs: every kernel evaluates all pairs of a frame, as the reference does.  When
-// the cutoff is short against the box (mdx_rdf_create decides), the frames are first
-// sorted in space -- rdf_sort_kernel permutes the atoms of every species along a Z-order
-// curve of cells, frame by frame, and records the bounding box of every tile of 256 atoms
-// -- and the fast kernel skips the frames of a tile pair whose boxes are further apart,
-// over the periodic images, than the cutoff plus a margin.  The pair set of a frame does
-// not depend on the order of the atoms within a species, so the counts are unchanged.
+// Sorted frames: every kernel evaluates all pairs of a frame, as the reference does.  For
+// species of many tiles (mdx_rdf_create decides) the frames are first sorted in space --
+// rdf_sort_kernel permutes the atoms of every species along a Hilbert curve of cells, frame
+// by frame, and records the bounding boxes of every tile of 256 atoms and of its quarters --
+// and the fast kernel (a) leaves out the minimum-image fold of a component wherever the
+// boxes of the two 64-atom groups show that no difference exceeds half a box length, and
+// (b) when the cutoff is short against the box, skips the frames of a tile pair (and the
+// quarters of a j-tile) whose boxes are further apart, over the periodic images, than the
+// cutoff plus a margin.  The pair set of a frame does not depend on the order of the atoms
+// within a species, so the counts are unchanged.
 //
 // Three pair functions produce identical bins:
 //   literal : the reference's float32 operations one by one (IEEE divide, rint,
