@@ -236,3 +236,27 @@ def test_sorted_frames_with_the_tile_pairs_sharded(gpu, monkeypatch, cutoff, nbi
     eng.close()
     ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
     np.testing.assert_array_equal(got, ref)
+
+
+def test_two_engines_with_different_lds_needs_alive_at_once(gpu):
+    """The kernels' LDS allowance is a property of the kernel, not of the engine: an engine
+    with many bins (120 KB of LDS per block) and sorted frames must still launch after an
+    engine with few bins and a small species has been created, and the other way round."""
+    rng = np.random.default_rng(5)
+    big_n, big_box, big_cut, big_bins = [2600, 2300], [30.0] * 3, np.float32(14.9), 14900
+    small_n, small_box, small_cut, small_bins = [300], [12.0] * 3, np.float32(5.0), 50
+    big_pos = [(rng.random((n, 2, 3)) * 30.0).astype(np.float32) for n in big_n]
+    small_pos = [(rng.random((n, 2, 3)) * 12.0).astype(np.float32) for n in small_n]
+    big = gpu.RdfEngine(big_n, big_box, big_cut, big_bins)
+    small = gpu.RdfEngine(small_n, small_box, small_cut, small_bins)
+    big.accumulate(big_pos)
+    small.accumulate(small_pos)
+    big.accumulate(big_pos)
+    got_big, got_small = big.read(), small.read()
+    big.close()
+    small.close()
+    ref_big = c_oracle.rdf_hist(np.concatenate(big_pos, 0), big_n, big_box, big_cut, big_bins)
+    ref_small = c_oracle.rdf_hist(np.concatenate(small_pos, 0), small_n, small_box, small_cut,
+                                  small_bins)
+    np.testing.assert_array_equal(got_big, 2 * ref_big)
+    np.testing.assert_array_equal(got_small, ref_small)
