@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
     uint32_t dst = first;
     unsigned long long remaining = __ballot(taken > 1u);
 #ifdef MDX_TIMING_SWITCHES
-    if (p.timing_mask >= 100) { remaining = 0ull; dst = i; }
+    if (p.timing_mask == 100 || p.timing_mask == 101) { remaining = 0ull; dst = i; }
 #endif
     while (remaining != 0ull) {
       const int leader = __builtin_ctzll(remaining);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   for (int i = sp.used + tid; i < slots; i += 256)
     for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
 #ifdef MDX_TIMING_SWITCHES
-  if (p.timing_mask >= 101) return;
+  if (p.timing_mask == 101) return;
 #endif
   __syncthreads();  // the block reads back what it wrote
   for (int t = 0; t < sp.tiles; ++t) {
@@ -691,6 +691,9 @@ struct FastRegs {
   int last_bin;     // nbins - 1
   uint32_t shift;   // frac_bits - 2: position bits -> byte offset of the bin's LDS word
   uint32_t dump;    // the lane's dump position (nbins + 1 + lane, every fraction bit set)
+#ifdef MDX_TIMING_SWITCHES
+  int drop_noted;   // timing only: noted pairs are never resolved (wrong counts)
+#endif
 };
 
 constexpr int kQueueSlots = 8;  // near-edge pairs a lane can note before they are resolved
@@ -704,6 +707,12 @@ __device__ __forceinline__ void fast_resolve_queue(
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
     float hx, float hy, float hz, float scale, float magic, uint32_t *__restrict__ hist,
     const float *__restrict__ g_thr, const FastRegs &r) {
+#ifdef MDX_TIMING_SWITCHES
+  if (r.drop_noted) {
+    count = 0;
+    return;
+  }
+#endif
   while (__any(count > 0)) {
     if (count > 0) {
       --count;
@@ -900,7 +909,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
 #ifdef MDX_TIMING_SWITCHES
     const int mask = (p.timing_mask >= 0 && p.timing_mask < 8)
                          ? p.timing_mask
-                         : (p.timing_mask >= 100 ? 7 : static_cast<int>((masks >> (3 * q)) & 7u));
+                         : static_cast<int>((masks >> (3 * q)) & 7u);
 #else
     const int mask = static_cast<int>((masks >> (3 * q)) & 7u);
 #endif
@@ -993,6 +1002,9 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   r.shift = in_vgpr(p.fast_frac_bits - 2u);
   // position nbins + 1 + lane: 64 distinct words, so the lanes of a wave never collide there
   r.dump = p.fast_dump_bits + (static_cast<uint32_t>(tid & 63) << p.fast_frac_bits);
+#ifdef MDX_TIMING_SWITCHES
+  r.drop_noted = p.timing_mask == 200;
+#endif
 
   // Adds the block's LDS counts of `key` to the device histogram and clears them.
   auto flush = [&](int key) {
