@@ -112,6 +112,7 @@ struct RdfParams {
   int fast_ok;               // 0: the bound is too wide for this geometry, do not use
   float cull_gap2;           // tile pairs with a squared box gap above this hold no pair in reach
   int cull_on;               // sorted frames: skip what the boxes put out of reach
+  int fast_queue_slots;      // bytes of a lane's queue of noted pairs
 #ifdef MDX_TIMING_SWITCHES
   int timing_mask;           // >= 0: every quarter takes this loop variant (wrong counts)
 #endif
@@ -691,13 +692,19 @@ struct FastRegs {
   int last_bin;     // nbins - 1
   uint32_t shift;   // frac_bits - 2: position bits -> byte offset of the bin's LDS word
   uint32_t dump;    // the lane's dump position (nbins + 1 + lane, every fraction bit set)
+  int queue_slots;  // entries of a lane's queue (a constant of the kernel's instantiation)
 #ifdef MDX_TIMING_SWITCHES
   int drop_noted;   // timing only: noted pairs are never resolved (wrong counts)
 #endif
 };
 
-constexpr int kQueueSlots = 8;  // near-edge pairs a lane can note before they are resolved
-constexpr int kQueueBytes = kQueueSlots;  // per lane: one byte per entry, the j-atom
+// Near-edge pairs a lane can note before they are resolved (one byte each, the j-atom).  A
+// full queue is drained in the middle of the j loop; with sorted frames a lane whose whole
+// tile is within the cutoff notes 1.25 pairs per tile on average, and some lane of the 256
+// passes four in almost every second tile but eight next to never.  The longer queue is
+// taken when it does not cost a block per compute unit (mdx_rdf_create).
+constexpr int kQueueSlotsShort = 8;
+constexpr int kQueueSlotsLong = 12;
 
 // Resolves the noted pairs of every lane: the hot loop has already counted them in the
 // bin of the approximate position (if that was below the cutoff); here the literal
@@ -817,7 +824,7 @@ __device__ __forceinline__ void fast_j_range(
         }
       }
       // a lane has room for four more pairs or everything is resolved now
-      if (__any(count > kQueueSlots - 4))
+      if (__any(count > r.queue_slots - 4))
         fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
                            hist, g_thr, r);
     }
@@ -963,7 +970,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
 // pace.  Frames that are not "compact" are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] (bins, the overflow bin, kDumpWords dump words) |
-// uint8 queue[kTile][kQueueSlots] | uint32 claim.
+// uint8 queue[kTile][kSlots] | uint32 claim.
 constexpr int kWorkLists = 8;
 
 // The loop needs every wave a SIMD can hold to hide its dependent chains (sub, sub, mul,
@@ -972,6 +979,7 @@ constexpr int kWorkLists = 8;
 // registers, which caps a SIMD at seven waves (800 scalar registers, allocated in
 // sixteens); asked for eight it keeps 72 and moves the rest, set-up values of the outer
 // loops, into lanes of a vector register.
+template <int kSlots>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void rdf_fast_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
     int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
@@ -981,9 +989,9 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   const int tid = threadIdx.x;
-  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kQueueBytes;
+  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kSlots;
   uint32_t *claim = reinterpret_cast<uint32_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words) +
-                                                 static_cast<size_t>(kTile) * kQueueBytes);
+                                                 static_cast<size_t>(kTile) * kSlots);
 
   const float hx = in_vgpr(p.half_box[0]);
   const float hy = in_vgpr(p.half_box[1]);
@@ -1002,6 +1010,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   r.shift = in_vgpr(p.fast_frac_bits - 2u);
   // position nbins + 1 + lane: 64 distinct words, so the lanes of a wave never collide there
   r.dump = p.fast_dump_bits + (static_cast<uint32_t>(tid & 63) << p.fast_frac_bits);
+  r.queue_slots = kSlots;
 #ifdef MDX_TIMING_SWITCHES
   r.drop_noted = p.timing_mask == 200;
 #endif
@@ -1550,7 +1559,10 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
     MDX_TRY(h->d_counter.reserve(sizeof(unsigned int) * kWorkLists));
     MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int) * kWorkLists, stream));
     const int64_t blocks = std::min<int64_t>(h->fast_blocks, std::max<int64_t>(n_chunks, kWorkLists));
-    hipLaunchKernelGGL(rdf_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
+    const auto kernel = h->params.fast_queue_slots == kQueueSlotsLong
+                            ? rdf_fast_kernel<kQueueSlotsLong>
+                            : rdf_fast_kernel<kQueueSlotsShort>;
+    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
                        h->fast_lds_bytes, stream, image, h->n_pad, nf,
                        frames_per_chunk, static_cast<int>(n_groups),
                        static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),
@@ -1902,18 +1914,33 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 
   if (!literal && p.fast_ok) {
     h->fast_lds_hist_words = (nbins + 1 + kDumpWords + 3) & ~3;
-    h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
-                        static_cast<size_t>(kTile) * kQueueBytes + 16;
+    // LDS of a block with queues of `slots` entries, and the blocks of it a compute unit's
+    // 160 KiB hold (the kernel is built for eight)
+    auto lds_with = [&](int slots) {
+      return 4 * static_cast<size_t>(h->fast_lds_hist_words) + static_cast<size_t>(kTile) * slots +
+             16;
+    };
+    auto blocks_with = [&](int slots) {
+      return std::min<size_t>(8, (160 * 1024) / lds_with(slots));
+    };
+    p.fast_queue_slots = blocks_with(kQueueSlotsLong) == blocks_with(kQueueSlotsShort)
+                             ? kQueueSlotsLong
+                             : kQueueSlotsShort;
+    h->fast_lds_bytes = lds_with(p.fast_queue_slots);
+    const void *fast_kernel =
+        p.fast_queue_slots == kQueueSlotsLong
+            ? reinterpret_cast<const void *>(rdf_fast_kernel<kQueueSlotsLong>)
+            : reinterpret_cast<const void *>(rdf_fast_kernel<kQueueSlotsShort>);
     if (h->fast_lds_bytes <= 160 * 1024) {
-      MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rdf_fast_kernel),
+      MDX_HIP(hipFuncSetAttribute(fast_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(h->fast_lds_bytes)));
       hipFuncAttributes attr;
-      MDX_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(rdf_fast_kernel)));
+      MDX_HIP(hipFuncGetAttributes(&attr, fast_kernel));
       int per_cu = 0;
       if (attr.sharedSizeBytes == 0)  // the histogram then starts at LDS address 0
         MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-          &per_cu, reinterpret_cast<const void *>(rdf_fast_kernel), kTile, h->fast_lds_bytes));
+          &per_cu, fast_kernel, kTile, h->fast_lds_bytes));
       hipDeviceProp_t prop;
       MDX_HIP(hipGetDeviceProperties(&prop, h->device));
       h->fast_blocks = per_cu * prop.multiProcessorCount;

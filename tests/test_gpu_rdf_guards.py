@@ -260,3 +260,29 @@ def test_two_engines_with_different_lds_needs_alive_at_once(gpu):
                                   small_bins)
     np.testing.assert_array_equal(got_big, 2 * ref_big)
     np.testing.assert_array_equal(got_small, ref_small)
+
+
+@pytest.mark.parametrize("nbins", [4000, 4400])
+def test_both_queue_lengths_drain_correctly(gpu, nbins):
+    """A lane notes its near-edge pairs in a queue of 12 entries, or of 8 when the longer
+    one would cost a block per compute unit (4 284 to 4 539 bins); a full queue is drained in
+    the middle of the j loop.  Atoms on a lattice whose distances sit on bin edges fill the
+    queues many times over, in sorted frames (5 000 atoms per species) and with every loop
+    variant in play."""
+    rng = np.random.default_rng(nbins)
+    cutoff = np.float32(20.0)          # bin width 0.005 / 0.004545: lattice distances on edges
+    box, n_per_species = [44.0] * 3, [5000, 4100]
+    grid = np.arange(0, 88, dtype=np.float32) * np.float32(0.5)
+    pos = []
+    for n in n_per_species:
+        cells = rng.choice(88 ** 3, size=n, replace=False)
+        xyz = np.stack([grid[cells % 88], grid[cells // 88 % 88], grid[cells // 7744]], axis=1)
+        pos.append(np.repeat(xyz[:, None, :], 2, axis=1).astype(np.float32))
+        pos[-1][:, 1] += (rng.random((n, 3)) * 1e-3).astype(np.float32)  # frame 1: just off
+    eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+    eng.accumulate(pos)
+    got = eng.read()
+    eng.close()
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
+    np.testing.assert_array_equal(got, ref)
+    assert ref.sum() > 0
