@@ -48,22 +48,39 @@ def fold_half(r, h):
     return (h - np.abs(t)).astype(F32)
 
 
-def fast_bits(xi, xj, plan, sqrt_ulps=0):
+def fast_bits(xi, xj, plan, sqrt_ulps=0, fold=7):
     """Bits of the kernel's position float for pairs ``xi``, ``xj`` ([n, 3] float32).
 
     ``sqrt_ulps`` moves the square root by that many float32 steps from the correctly
-    rounded value (the hardware instruction is accurate to one)."""
+    rounded value (the hardware instruction is accurate to one).  ``fold`` (an integer or
+    one per pair): bit c set = component c goes through the minimum-image fold, clear = the
+    loop variant that takes the difference as it is, which the kernel picks only where
+    ``|x_j - x_i| <= L_c / 2`` is known for the whole group of pairs (``foldable_mask``)."""
     xi = np.asarray(xi, F32)
     xj = np.asarray(xj, F32)
     h = np.asarray(plan["half_box"], F32)
     r = (xj - xi).astype(F32)
-    m = [fold_half(r[:, c], h[c]) for c in range(3)]
+    fold = np.broadcast_to(np.asarray(fold, np.int64), (len(r),))
+    m = [np.where((fold >> c) & 1 == 1, fold_half(r[:, c], h[c]), r[:, c]).astype(F32)
+         for c in range(3)]
     s = fma32(m[2], m[2], fma32(m[1], m[1], (m[0] * m[0]).astype(F32)))
     root = np.sqrt(s).astype(F32)
     for _ in range(abs(int(sqrt_ulps))):
         root = np.nextafter(root, F32(np.inf) if sqrt_ulps > 0 else F32(0.0)).astype(F32)
     out = fma32(root, F32(plan["scale"]), F32(plan["magic"]))
     return out.view(np.uint32)
+
+
+def foldable_mask(xi, xj, plan):
+    """Per pair, the components the kernel could not leave unfolded: bit c set when
+    ``|fl(x_j - x_i)|`` exceeds ``L_c / 2`` (the box criterion of the kernel guarantees the
+    opposite for every pair of a group before it drops a fold)."""
+    xi = np.asarray(xi, F32)
+    xj = np.asarray(xj, F32)
+    h = np.asarray(plan["half_box"], F32)
+    r = (xj - xi).astype(F32)
+    need = np.abs(r) > h[None, :]
+    return (need[:, 0] * 1 + need[:, 1] * 2 + need[:, 2] * 4).astype(np.int64)
 
 
 def literal_bins(xi, xj, box, cutoff, nbins):
@@ -100,15 +117,16 @@ def stored_position(bits, plan):
     return (np.asarray(bits, np.uint32) & np.uint32(0x7FFFFF)).astype(F64) / F64(1 << frac_bits)
 
 
-def check_pairs(xi, xj, box, cutoff, nbins, plan):
+def check_pairs(xi, xj, box, cutoff, nbins, plan, fold=7):
     """Holds the kernel's decisions to the literal rule for every pair and every modelled
-    square-root result; returns counts for the report.  Raises AssertionError."""
+    square-root result; returns counts for the report.  Raises AssertionError.  ``fold``:
+    the loop variant per pair (see ``fast_bits``)."""
     kept, bins, pos = literal_bins(xi, xj, box, cutoff, nbins)
     grid = 1.0 / (1 << int(plan["frac_bits"]))
     width = float(plan["edge_units"]) * grid  # 2 * shift
     report = {"pairs": int(len(kept)), "resolved": 0, "worst_low": 0.0, "worst_high": 0.0}
     for ulps in (-1, 0, 1):
-        bits = fast_bits(xi, xj, plan, sqrt_ulps=ulps)
+        bits = fast_bits(xi, xj, plan, sqrt_ulps=ulps, fold=fold)
         dropped, near, counted = kernel_decision(bits, plan)
         bad_drop = dropped & kept
         assert not bad_drop.any(), (

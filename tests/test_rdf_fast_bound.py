@@ -73,11 +73,22 @@ def test_fast_kernel_decisions_equal_the_literal_rule(box, cutoff, nbins):
         model.uniform_pairs(box, 200_000, rng),
     ]
     worst_high = 0.0
+    unfolded = 0
     for xi, xj in sets:
         report = model.check_pairs(xi, xj, box, cutoff32, nbins, plan)
         total["pairs"] += report["pairs"]
         total["resolved"] += report["resolved"]
         worst_high = max(worst_high, report["worst_high"])
+        # the loop variants that leave out the fold of a component: every fold dropped that
+        # the pair admits (differences of at most half a box length, the ones exactly at
+        # half a box included), and a random choice between that and all of them
+        least = model.foldable_mask(xi, xj, plan)
+        some = least | rng.integers(0, 8, len(least))
+        for fold in (least, some):
+            report = model.check_pairs(xi, xj, box, cutoff32, nbins, plan, fold=fold)
+            worst_high = max(worst_high, report["worst_high"])
+        unfolded += int(np.sum(least != 7))
+    assert unfolded > 10_000
     # the edge sets must really have landed inside the band the kernel re-evaluates
     assert total["resolved"] > 1000
     grid = 1.0 / (1 << plan["frac_bits"])
