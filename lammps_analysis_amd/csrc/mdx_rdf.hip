@@ -53,7 +53,7 @@
 //             literal one is bounded on the host (rdf_fast_setup), and only pairs
 //             whose position lies within that bound of a bin edge (well under 1 %)
 //             are evaluated again, literally, against the thresholds.  Those pairs
-//             are noted in a lane-private LDS queue and corrected after the j loop,
+//             are noted in a queue of their wave in LDS and corrected in batches of 64,
 //             so the hot loop has no divergent slow path.
 //
 // This file must be compiled with -ffp-contract=off: a fused multiply-add in the
@@ -112,7 +112,6 @@ struct RdfParams {
   int fast_ok;               // 0: the bound is too wide for this geometry, do not use
   float cull_gap2;           // tile pairs with a squared box gap above this hold no pair in reach
   int cull_on;               // sorted frames: skip what the boxes put out of reach
-  int fast_queue_slots;      // bytes of a lane's queue of noted pairs
 #ifdef MDX_TIMING_SWITCHES
   int timing_mask;           // >= 0: every quarter takes this loop variant (wrong counts)
 #endif
@@ -692,60 +691,69 @@ struct FastRegs {
   int last_bin;     // nbins - 1
   uint32_t shift;   // frac_bits - 2: position bits -> byte offset of the bin's LDS word
   uint32_t dump;    // the lane's dump position (nbins + 1 + lane, every fraction bit set)
-  int queue_slots;  // entries of a lane's queue (a constant of the kernel's instantiation)
 #ifdef MDX_TIMING_SWITCHES
   int drop_noted;   // timing only: noted pairs are never resolved (wrong counts)
 #endif
 };
 
-// Near-edge pairs a lane can note before they are resolved (one byte each, the j-atom).  A
-// full queue is drained in the middle of the j loop; with sorted frames a lane whose whole
-// tile is within the cutoff notes 1.25 pairs per tile on average, and some lane of the 256
-// passes four in almost every second tile but eight next to never.  The longer queue is
-// taken when it does not cost a block per compute unit (mdx_rdf_create).
-constexpr int kQueueSlotsShort = 8;
-constexpr int kQueueSlotsLong = 12;
+// Entries of a wave's queue of noted pairs (16 bits: i-lane << 8 | j-atom).  One iteration
+// of the j loop can add 256; full batches of 64 are resolved as soon as there are any, so
+// fewer than 64 entries are left when the next iteration starts.
+constexpr int kWaveQueue = 256 + 64;
 
-// Resolves the noted pairs of every lane: the hot loop has already counted them in the
-// bin of the approximate position (if that was below the cutoff); here the literal
-// squared distance decides, and the count is moved when the two disagree.
-__device__ __forceinline__ void fast_resolve_queue(
-    int &count, uint8_t *__restrict__ queue, uint32_t masks, float xi, float yi, float zi,
-    const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
-    float hx, float hy, float hz, float scale, float magic, uint32_t *__restrict__ hist,
-    const float *__restrict__ g_thr, const FastRegs &r) {
-#ifdef MDX_TIMING_SWITCHES
-  if (r.drop_noted) {
-    count = 0;
-    return;
+// Resolves n <= 64 noted pairs of a wave, entries [first, first + n) of its queue, one per
+// lane: the hot loop has already counted them in the bin of the approximate position (if
+// that was below the cutoff); here the literal squared distance decides, and the count is
+// moved when the two disagree.  The i-atom of an entry comes from its lane's registers.
+__device__ __forceinline__ void fast_resolve_batch(
+    int first, int n, const uint16_t *__restrict__ queue, uint32_t masks, int lane, float xi,
+    float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
+    const float *__restrict__ zj, float hx, float hy, float hz, float scale, float magic,
+    uint32_t *__restrict__ hist, const float *__restrict__ g_thr, const FastRegs &r) {
+  const int entry = queue[first + (lane < n ? lane : 0)];
+  const int j = entry & 255;
+  const int i_lane = entry >> 8;
+  const float pxi = __shfl(xi, i_lane), pyi = __shfl(yi, i_lane), pzi = __shfl(zi, i_lane);
+  if (lane < n) {
+    const float pxj = xj[j], pyj = yj[j], pzj = zj[j];
+    // the components the hot loop folded for this j-atom's quarter of the tile
+    const int fold = static_cast<int>((masks >> (3 * (j >> 6))) & 7u);
+    const uint32_t bits =
+        fast_position_bits(pxi, pyi, pzi, pxj, pyj, pzj, hx, hy, hz, scale, magic, fold);
+    const bool counted = bits < r.keep_bits;
+    const int guess = static_cast<int>((bits & 0x7FFFFFu) >> r.frac_bits);
+    const float s = literal_wrapped_s(pxi, pyi, pzi, pxj, pyj, pzj, r.box);
+    int e = min(max(guess, 0), r.last_bin);
+    const float lo = g_thr[e];
+    const float hi = g_thr[e + 1];
+    e += (s >= hi) ? 1 : 0;
+    e -= (s < lo) ? 1 : 0;
+    const bool kept = s < r.s_cut;
+    if (counted && !(kept && e == guess)) atomicSub(&hist[guess], 1u);
+    if (kept && !(counted && e == guess)) atomicAdd(&hist[e], 1u);
   }
+}
+
+// Resolves everything the wave has noted (count entries; the end of a tile).
+__device__ __forceinline__ void fast_resolve_queue(
+    int &count, const uint16_t *__restrict__ queue, uint32_t masks, int lane, float xi, float yi,
+    float zi, const float *__restrict__ xj, const float *__restrict__ yj,
+    const float *__restrict__ zj, float hx, float hy, float hz, float scale, float magic,
+    uint32_t *__restrict__ hist, const float *__restrict__ g_thr, const FastRegs &r) {
+#ifdef MDX_TIMING_SWITCHES
+  if (r.drop_noted) count = 0;
 #endif
-  while (__any(count > 0)) {
-    if (count > 0) {
-      --count;
-      const int j = queue[count];
-      const float pxj = xj[j], pyj = yj[j], pzj = zj[j];
-      // the components the hot loop folded for this j-atom's quarter of the tile
-      const int fold = static_cast<int>((masks >> (3 * (j >> 6))) & 7u);
-      const uint32_t bits =
-          fast_position_bits(xi, yi, zi, pxj, pyj, pzj, hx, hy, hz, scale, magic, fold);
-      const bool counted = bits < r.keep_bits;
-      const int guess = static_cast<int>((bits & 0x7FFFFFu) >> r.frac_bits);
-      const float s = literal_wrapped_s(xi, yi, zi, pxj, pyj, pzj, r.box);
-      int e = min(max(guess, 0), r.last_bin);
-      const float lo = g_thr[e];
-      const float hi = g_thr[e + 1];
-      e += (s >= hi) ? 1 : 0;
-      e -= (s < lo) ? 1 : 0;
-      const bool kept = s < r.s_cut;
-      if (counted && !(kept && e == guess)) atomicSub(&hist[guess], 1u);
-      if (kept && !(counted && e == guess)) atomicAdd(&hist[e], 1u);
-    }
+  while (count > 0) {
+    const int n = min(count, 64);
+    count -= n;
+    fast_resolve_batch(count, n, queue, masks, lane, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale,
+                       magic, hist, g_thr, r);
   }
 }
 
 // The j-atoms [j_begin, j_end) of one (tile pair, frame) item: lane = i-atom.  Near-edge
-// pairs are noted in the lane's queue (`count` entries so far) for the caller to resolve.
+// pairs are noted in the wave's queue (`count` entries so far, uniform over the wave); full
+// batches of 64 are resolved on the spot, the rest is left for the caller.
 // The loop reads one iteration ahead: on entry nx, ny, nz hold the atoms j_begin .. j_begin
 // + 3, on exit the atoms j_end .. j_end + 3 when j_end < j_limit (the caller's next range
 // then starts without waiting for a load).  kFold: the components this range folds; masks:
@@ -756,7 +764,7 @@ __device__ __forceinline__ void fast_j_range(
     int j_begin, int j_end, int j_limit, float4 &nx, float4 &ny, float4 &nz, int &count,
     uint32_t masks, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
-    uint32_t *__restrict__ hist, uint8_t *__restrict__ queue, const float *__restrict__ g_thr,
+    uint32_t *__restrict__ hist, uint16_t *__restrict__ queue, const float *__restrict__ g_thr,
     const RdfParams &p, const FastRegs &r, int tid, float hx, float hy, float hz, float scale, float magic,
     uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
   const uint32_t shift = r.shift;
@@ -815,18 +823,33 @@ __device__ __forceinline__ void fast_j_range(
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) lds_count((bits[u] >> shift) & addr_mask, one);
-    if (__builtin_expect(near[0] || near[1] || near[2] || near[3], 0)) {
+    // Noting: the wave appends its near-edge pairs to its queue, pair slot by pair slot, the
+    // lanes of a slot in lane order (count is uniform over the wave).
+    unsigned long long noted[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) noted[u] = __ballot(near[u]);
+    if (__builtin_expect((noted[0] | noted[1] | noted[2] | noted[3]) != 0ull, 0)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (near[u]) {
-          queue[count] = static_cast<uint8_t>(j0 + u);
-          ++count;
+        if (noted[u] != 0ull) {
+          const uint32_t below = __builtin_amdgcn_mbcnt_hi(
+              static_cast<uint32_t>(noted[u] >> 32),
+              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(noted[u]), 0u));
+          if (near[u])
+            queue[count + static_cast<int>(below)] =
+                static_cast<uint16_t>(((tid & 63) << 8) | (j0 + u));
+          count += __popcll(noted[u]);
         }
       }
-      // a lane has room for four more pairs or everything is resolved now
-      if (__any(count > r.queue_slots - 4))
-        fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic,
-                           hist, g_thr, r);
+#ifdef MDX_TIMING_SWITCHES
+      if (r.drop_noted) count = 0;
+#endif
+      // full batches are resolved at once: fewer than 64 entries stay behind
+      while (count >= 64) {
+        count -= 64;
+        fast_resolve_batch(count, 64, queue, masks, tid & 63, xi, yi, zi, xj, yj, zj, hx, hy, hz,
+                           scale, magic, hist, g_thr, r);
+      }
     }
   }
 }
@@ -836,7 +859,7 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one) {
   const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
@@ -850,8 +873,8 @@ __device__ __forceinline__ void fast_tile_loop(
   fast_j_range<kDiag>(j_begin, j_end, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj,
                       hist, queue, g_thr, p, r, tid, hx, hy, hz, scale, magic, addr_mask,
                       frac_mask, one);
-  fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
-                     g_thr, r);
+  fast_resolve_queue(count, queue, masks, tid & 63, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale,
+                     magic, hist, g_thr, r);
 }
 
 // Which components of the pairs (64 i-atoms in ibox, 64 j-atoms of a quarter of the j-tile)
@@ -895,7 +918,7 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop_sorted(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint8_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one, const float *__restrict__ ibox,
     const float *__restrict__ jboxes) {
@@ -953,8 +976,8 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
     }
 #undef MDX_FOLD_CASE
   }
-  fast_resolve_queue(count, queue, masks, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale, magic, hist,
-                     g_thr, r);
+  fast_resolve_queue(count, queue, masks, tid & 63, xi, yi, zi, xj, yj, zj, hx, hy, hz, scale,
+                     magic, hist, g_thr, r);
 }
 
 // Persistent blocks with shared work counters.  A chunk is up to frames_per_chunk
@@ -970,7 +993,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
 // pace.  Frames that are not "compact" are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] (bins, the overflow bin, kDumpWords dump words) |
-// uint8 queue[kTile][kSlots] | uint32 claim.
+// uint16 queue[4 waves][kWaveQueue] | uint32 claim.
 constexpr int kWorkLists = 8;
 
 // The loop needs every wave a SIMD can hold to hide its dependent chains (sub, sub, mul,
@@ -979,7 +1002,6 @@ constexpr int kWorkLists = 8;
 // registers, which caps a SIMD at seven waves (800 scalar registers, allocated in
 // sixteens); asked for eight it keeps 72 and moves the rest, set-up values of the outer
 // loops, into lanes of a vector register.
-template <int kSlots>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void rdf_fast_kernel(
     const float *__restrict__ packed, int64_t n_pad, int n_frames, int frames_per_chunk,
     int n_groups, int n_pairs, const TilePair *__restrict__ pairs,
@@ -989,9 +1011,10 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t *hist = reinterpret_cast<uint32_t *>(lds_raw);
   const int tid = threadIdx.x;
-  uint8_t *queue = lds_raw + 4 * static_cast<size_t>(lds_hist_words) + tid * kSlots;
+  uint16_t *queue = reinterpret_cast<uint16_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words)) +
+                    (tid >> 6) * kWaveQueue;
   uint32_t *claim = reinterpret_cast<uint32_t *>(lds_raw + 4 * static_cast<size_t>(lds_hist_words) +
-                                                 static_cast<size_t>(kTile) * kSlots);
+                                                 static_cast<size_t>(kTile / 64) * kWaveQueue * 2);
 
   const float hx = in_vgpr(p.half_box[0]);
   const float hy = in_vgpr(p.half_box[1]);
@@ -1010,7 +1033,6 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   r.shift = in_vgpr(p.fast_frac_bits - 2u);
   // position nbins + 1 + lane: 64 distinct words, so the lanes of a wave never collide there
   r.dump = p.fast_dump_bits + (static_cast<uint32_t>(tid & 63) << p.fast_frac_bits);
-  r.queue_slots = kSlots;
 #ifdef MDX_TIMING_SWITCHES
   r.drop_noted = p.timing_mask == 200;
 #endif
@@ -1559,10 +1581,7 @@ int histogram_frame_block(mdx_rdf_s *h, int dtype, const void *const *species_pt
     MDX_TRY(h->d_counter.reserve(sizeof(unsigned int) * kWorkLists));
     MDX_HIP(hipMemsetAsync(h->d_counter.ptr, 0, sizeof(unsigned int) * kWorkLists, stream));
     const int64_t blocks = std::min<int64_t>(h->fast_blocks, std::max<int64_t>(n_chunks, kWorkLists));
-    const auto kernel = h->params.fast_queue_slots == kQueueSlotsLong
-                            ? rdf_fast_kernel<kQueueSlotsLong>
-                            : rdf_fast_kernel<kQueueSlotsShort>;
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
+    hipLaunchKernelGGL(rdf_fast_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kTile),
                        h->fast_lds_bytes, stream, image, h->n_pad, nf,
                        frames_per_chunk, static_cast<int>(n_groups),
                        static_cast<int>(h->n_pairs_shard), h->d_pairs_shard.as<TilePair>(),
@@ -1914,23 +1933,9 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
 
   if (!literal && p.fast_ok) {
     h->fast_lds_hist_words = (nbins + 1 + kDumpWords + 3) & ~3;
-    // LDS of a block with queues of `slots` entries, and the blocks of it a compute unit's
-    // 160 KiB hold (the kernel is built for eight)
-    auto lds_with = [&](int slots) {
-      return 4 * static_cast<size_t>(h->fast_lds_hist_words) + static_cast<size_t>(kTile) * slots +
-             16;
-    };
-    auto blocks_with = [&](int slots) {
-      return std::min<size_t>(8, (160 * 1024) / lds_with(slots));
-    };
-    p.fast_queue_slots = blocks_with(kQueueSlotsLong) == blocks_with(kQueueSlotsShort)
-                             ? kQueueSlotsLong
-                             : kQueueSlotsShort;
-    h->fast_lds_bytes = lds_with(p.fast_queue_slots);
-    const void *fast_kernel =
-        p.fast_queue_slots == kQueueSlotsLong
-            ? reinterpret_cast<const void *>(rdf_fast_kernel<kQueueSlotsLong>)
-            : reinterpret_cast<const void *>(rdf_fast_kernel<kQueueSlotsShort>);
+    h->fast_lds_bytes = 4 * static_cast<size_t>(h->fast_lds_hist_words) +
+                        static_cast<size_t>(kTile / 64) * kWaveQueue * sizeof(uint16_t) + 16;
+    const void *fast_kernel = reinterpret_cast<const void *>(rdf_fast_kernel);
     if (h->fast_lds_bytes <= 160 * 1024) {
       MDX_HIP(hipFuncSetAttribute(fast_kernel,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -263,12 +263,12 @@ def test_two_engines_with_different_lds_needs_alive_at_once(gpu):
 
 
 @pytest.mark.parametrize("nbins", [4000, 4400])
-def test_both_queue_lengths_drain_correctly(gpu, nbins):
-    """A lane notes its near-edge pairs in a queue of 12 entries, or of 8 when the longer
-    one would cost a block per compute unit (4 284 to 4 539 bins); a full queue is drained in
-    the middle of the j loop.  Atoms on a lattice whose distances sit on bin edges fill the
-    queues many times over, in sorted frames (5 000 atoms per species) and with every loop
-    variant in play."""
+def test_noted_pairs_are_resolved_in_batches(gpu, nbins):
+    """A wave notes its near-edge pairs in a queue of 320 entries and resolves them 64 at a
+    time, in the middle of the j loop as soon as a batch is full.  Atoms on a lattice whose
+    distances sit on bin edges fill the queues many times over (up to 256 entries in one
+    iteration), in sorted frames (5 000 atoms per species) and with every loop variant in
+    play; two bin counts, the second with an LDS histogram close to a block's share."""
     rng = np.random.default_rng(nbins)
     cutoff = np.float32(20.0)          # bin width 0.005 / 0.004545: lattice distances on edges
     box, n_per_species = [44.0] * 3, [5000, 4100]
