@@ -112,7 +112,7 @@ def fold_free_share(frame: list, box: float) -> dict:
     for pos in frame:
         used = len(pos)
         bits = 1
-        while bits < 4 and (1 << (3 * (bits + 1))) * 8 <= used:
+        while bits < 4 and (1 << (3 * (bits + 1))) * 4 <= used:
             bits += 1
         per_axis = 1 << bits
         lo = pos.min(axis=0)

@@ -1876,8 +1876,8 @@ int mdx_rdf_create(mdx_rdf_t *handle, int n_species, const int64_t *n_per_specie
       sp.first_slot = static_cast<int32_t>(tile_first[s] * kTile);
       sp.used = static_cast<int32_t>(used);
       sp.tiles = static_cast<int32_t>(tile_count[s]);
-      sp.cell_bits = 1;  // about eight atoms per cell, 16 cells per axis at most
-      while (sp.cell_bits < 4 && (int64_t(1) << (3 * (sp.cell_bits + 1))) * 8 <= used)
+      sp.cell_bits = 1;  // four to thirty-two atoms per cell, 16 cells per axis at most
+      while (sp.cell_bits < 4 && (int64_t(1) << (3 * (sp.cell_bits + 1))) * 4 <= used)
         ++sp.cell_bits;
       table.push_back(sp);
       const double group_edge = std::cbrt(volume * std::min<double>(1.0, 64.0 / used));
