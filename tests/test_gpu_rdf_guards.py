@@ -286,3 +286,26 @@ def test_noted_pairs_are_resolved_in_batches(gpu, nbins):
     ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
     np.testing.assert_array_equal(got, ref)
     assert ref.sum() > 0
+
+
+def test_sort_placements_around_their_switch(gpu, monkeypatch):
+    """The sort kernel places a species of at most 12 288 atoms through an index list in
+    LDS and larger ones wave by wave; a crowded cell sends a small species the second way
+    too.  One species either side of the limit, and a species collapsed into one cell,
+    with the tile pairs in two shards (both placements must give the order of the input
+    within a cell, or the shards' tiles would differ)."""
+    monkeypatch.setenv("MDX_RDF_CULL", "1")
+    monkeypatch.setenv("MDX_RDF_UNFOLD", "1")
+    rng = np.random.default_rng(12288)
+    box, cutoff, nbins = [50.0] * 3, np.float32(6.0), 600
+    n_per_species = [12290, 12289, 3000]   # strict masks drop one atom each
+    pos = [(rng.random((n, 2, 3)) * 50.0).astype(np.float32) for n in n_per_species]
+    pos[2][:, :, :] = (np.float32(20.0) + rng.random((3000, 2, 3)) * 1.5).astype(np.float32)
+    eng = gpu.RdfEngine(n_per_species, box, cutoff, nbins)
+    for rank in range(2):
+        eng.accumulate(pos, shard_rank=rank, shard_count=2)
+    got = eng.read()
+    eng.close()
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, box, cutoff, nbins)
+    np.testing.assert_array_equal(got, ref)
+    assert ref.sum() > 0
