@@ -8,7 +8,6 @@ run() {
 }
 run sorted_masks_from_boxes || exit 1
 MDX_RDF_UNFOLD=0 run unsorted || exit 1
-MDX_RDF_TIMING_MASK=7 run sorted_quarters_all_folded || exit 1
-MDX_RDF_TIMING_MASK=15 run sorted_whole_tile_all_folded || exit 1
-MDX_RDF_TIMING_MASK=0 run sorted_quarters_nothing_folded || exit 1
-MDX_RDF_TIMING_MASK=8 run sorted_whole_tile_nothing_folded || exit 1
+MDX_RDF_TIMING_MASK=7 run sorted_all_folded || exit 1
+MDX_RDF_TIMING_MASK=0 run sorted_nothing_folded || exit 1
+MDX_RDF_FAST_NO_EDGE=1 run sorted_no_edge_band || exit 1
