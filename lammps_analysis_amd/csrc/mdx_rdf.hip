@@ -2126,7 +2126,7 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const void *const *species_pos, int dtype,
 
   // frames are processed in chunks bounded by the packed image size
   const size_t bytes_per_frame = sizeof(float) * 3 * static_cast<size_t>(h->n_pad);
-  int64_t chunk = static_cast<int64_t>((size_t(h->sort_frames ? 1 : 2) << 30) / bytes_per_frame);
+  int64_t chunk = static_cast<int64_t>((size_t(2) << 30) / bytes_per_frame);
   if (chunk < 1) chunk = 1;
   if (chunk > n_frames) chunk = n_frames;
   if (chunk > 32768) chunk = 32768;
