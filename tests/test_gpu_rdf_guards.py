@@ -262,13 +262,14 @@ def test_two_engines_with_different_lds_needs_alive_at_once(gpu):
     np.testing.assert_array_equal(got_small, ref_small)
 
 
-@pytest.mark.parametrize("nbins", [4000, 4400])
+@pytest.mark.parametrize("nbins", [4000, 4400, 4990])
 def test_noted_pairs_are_resolved_in_batches(gpu, nbins):
     """A wave notes its near-edge pairs in a queue of 320 entries and resolves them 64 at a
     time, in the middle of the j loop as soon as a batch is full.  Atoms on a lattice whose
     distances sit on bin edges fill the queues many times over (up to 256 entries in one
     iteration), in sorted frames (5 000 atoms per species) and with every loop variant in
-    play; two bin counts, the second with an LDS histogram close to a block's share."""
+    play; three bin counts: the second with an LDS histogram close to a block's share of a
+    compute unit, the third beyond it (seven blocks per unit)."""
     rng = np.random.default_rng(nbins)
     cutoff = np.float32(20.0)          # bin width 0.005 / 0.004545: lattice distances on edges
     box, n_per_species = [44.0] * 3, [5000, 4100]
