@@ -225,6 +225,40 @@ def test_rdf_calculator_streams_long_frame_runs_from_the_store(gpu, tmp_path, mo
                                           np.asarray(ref[key]["y"])[1:])
 
 
+def test_rdf_calculator_at_a_size_that_sorts_its_frames(gpu, tmp_path):
+    """2 600 + 2 500 atoms in a box of 44: the engine sorts such frames in space and leaves
+    out minimum-image folds.  Through ``exp.run`` by all three routes (a long run streamed
+    from the store, a frame list, the batch loop), counts from the C oracle on the sampled
+    frames and the oracle's normalisation."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(44)
+    box, n_step, n_na, n_cl = 44.0, 140, 2600, 2500
+    pos_na, pos_cl, _, _ = _nacl(rng, n_na, n_cl, n_step, box)
+    project = mds.Project(name="rdf_sorted", storage_path=tmp_path)
+    exp = project.add_experiment("NaCl", timestep=0.002, temperature=1400.0, units="metal")
+    _add(exp, {"Na": {mdsuite_properties.positions: pos_na},
+               "Cl": {mdsuite_properties.positions: pos_cl}}, n_step, box_l=[box] * 3)
+    stored = np.concatenate([np.swapaxes(pos_na, 0, 1), np.swapaxes(pos_cl, 0, 1)],
+                            axis=0).astype(np.float32)
+    n_particles = {"Na": n_na, "Cl": n_cl}
+    for n_cfg in (-1, 70, 4):
+        got = exp.run.RadialDistributionFunction(number_of_configurations=n_cfg, plot=False,
+                                                 strict_reference_masks=True)
+        args = orc_rdf.default_arguments([box] * 3, n_step, n_cfg)
+        counts = c_oracle.rdf_hist(stored, [n_na, n_cl], [box] * 3,
+                                   np.float32(args["cutoff"]), args["number_of_bins"],
+                                   frames=args["sample_configurations"], strict=True)
+        corr = orc_rdf.ideal_correction([box] * 3, args["cutoff"], args["number_of_bins"])
+        for key, row in zip(("Na_Na", "Na_Cl", "Cl_Cl"), counts):
+            a, b = key.split("_")
+            with np.errstate(divide="ignore", invalid="ignore"):
+                denominator = (args["number_of_configurations"] * (n_particles[b] / box ** 3)
+                               * corr * n_particles[a])
+                y = row.astype(float) * ((2 if a == b else 1) / denominator)
+            np.testing.assert_array_equal(np.asarray(got[key]["y"])[1:], y[1:], err_msg=key)
+        assert counts.sum() > 0
+
+
 def test_green_kubo_ionic_conductivity_chain(gpu, tmp_path):
     """Velocities -> IonicCurrent transformation (GPU reduction, float32 storage) ->
     windowed ACF, against the oracle chain."""
