@@ -265,7 +265,7 @@ def main() -> None:
     if args.frames_per_step > 0:
         fps = args.frames_per_step
     else:
-        fps = 16 if shard_tiles else max(1, TRAJECTORY_FRAMES // steps)
+        fps = 64 if shard_tiles else max(1, TRAJECTORY_FRAMES // steps)
     # the timed steps walk once through the resident trajectory (100 000 frames per rank
     # with the default step size); warm-up steps re-read its first blocks
     n_frames = fps * steps
