@@ -203,10 +203,11 @@ __host__ __device__ inline int curve_offset(int cell_bits) {
 // atoms at a time with one LDS atomic each -- a lane alone in its cell has its position;
 // lanes that share a cell are found with ballots and take the cell's positions lowest lane
 // first.  Both give the same order.
-// frame_lo holds the frame's smallest coordinate per component (the frame is compact:
-// every coordinate lies within one box length above it), so the cell grid follows a
-// trajectory that is not wrapped into [0, L).  Frames that are not compact are copied
-// unsorted (they go to the table kernel, which skips nothing); their boxes are never read.
+// frame_lo holds the frame's smallest coordinate per component, so the cell grid follows a
+// trajectory that is not wrapped into [0, L); what lies more than a box length above it
+// (frames of class 1, see rdf_extent_kernel) goes into the last cells.  Frames of class 0
+// are copied unsorted (they go to the table kernel, which skips nothing); their boxes are
+// never read.
 // Dynamic LDS: uint32 [5][n_cells] | uint16 list[used] (species of at most kSortIndexed).
 constexpr int kSortIndexed = 12288;
 constexpr uint32_t kSortCellMax = 64;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   const float *X = packed + static_cast<int64_t>(f) * 3 * n_pad + sp.first_slot;
   float *Y = sorted + static_cast<int64_t>(f) * 3 * n_pad + sp.first_slot;
   const int slots = sp.tiles * kTile;
-  if (frame_wrapped[f] != 2) {
+  if (frame_wrapped[f] == 0) {
     for (int c = 0; c < 3; ++c)
       for (int i = tid; i < slots; i += 256) Y[c * n_pad + i] = X[c * n_pad + i];
     return;
@@ -406,10 +407,11 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
   }
 }
 
-// Squared distance between two boxes (lo[3], hi[3]) over the periodic images of a compact
-// frame: per component the smallest gap between the intervals when one of them is moved by
-// -L, 0 or +L (coordinate differences of a compact frame are at most L, so no other image
-// can be the nearest).
+// Squared distance between two boxes (lo[3], hi[3]) over the periodic images of a frame
+// whose coordinate differences stay below 1.5 box lengths: per component the smallest gap
+// between the intervals when one of them is moved by -L, 0 or +L.  (A shift by two box
+// lengths leaves at least half a box length, and the skipping that asks for this gap is only
+// switched on for cutoffs below 0.45 of the shortest edge.)
 __device__ __forceinline__ float box_gap2(const float *__restrict__ a,
                                           const float *__restrict__ b, const RdfParams &p) {
   float sum = 0.0f;
@@ -448,8 +450,9 @@ __device__ __forceinline__ void pair_literal(float xi, float yi, float zi, float
 
 // Classifies every frame by the spread of its coordinates: 2 = "compact", every
 // coordinate difference is at most one box length (what a trajectory wrapped into the box
-// gives; the fast kernel's error bound assumes it); 1 = "wrapped", the differences stay
-// below t_far, so the minimum-image shift is at most one box length; 0 = neither.
+// gives); 1 = "wrapped", the differences stay below t_far (about 1.5 box lengths), so the
+// minimum-image shift is at most one box length (atoms that have left the box a little
+// since they were last wrapped) -- the fast kernel takes both; 0 = neither.
 // One block per frame; NaN padding is ignored by fminf/fmaxf.  frame_lo, if given, receives
 // the frame's smallest coordinate per component.
 __global__ __launch_bounds__(256) void rdf_extent_kernel(const float *__restrict__ packed,
@@ -616,7 +619,7 @@ __device__ __forceinline__ void table_tile_loop(float xi, float yi, float zi,
 // ----------------------------------------------------------------- fast kernel
 
 // Bits of the float that holds the approximate bin position of one pair, for frames
-// whose coordinate differences are at most one box length ("compact" frames).
+// whose coordinate differences stay below t_far, about 1.5 box lengths (classes 1 and 2).
 //   r = x_j - x_i (the literal difference), then per component
 //   m = h - ||r| - h|,  h = box / 2      (= min(|r|, box - |r|) up to two roundings)
 //   s = fma(mz, mz, fma(my, my, mx * mx)),  root = v_sqrt_f32(s)       (1 ulp)
@@ -991,7 +994,7 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
 // through the keys in step a block flushes its LDS histogram only a few times per launch
 // (on a key change and at the end).  Every block claims chunks with one global atomic
 // each until all eight lists are empty, so the launch drains evenly whatever the blocks'
-// pace.  Frames that are not "compact" are skipped (the table kernel takes them).
+// pace.  Frames of class 0 are skipped (the table kernel takes them).
 // LDS layout: uint32 hist[lds_hist_words] (bins, the overflow bin, kDumpWords dump words) |
 // uint16 queue[4 waves][kWaveQueue] | uint32 claim.
 constexpr int kWorkLists = 8;
@@ -1092,7 +1095,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       const int f_end = min(n_frames, f_begin + frames_per_chunk);
       const int64_t slot_i = static_cast<int64_t>(tp.tile_i) * kTile + tid;
       for (int f = f_begin; f < f_end; ++f) {
-        if (frame_wrapped[f] != 2) continue;  // compact frames only, see rdf_fast_setup
+        if (frame_wrapped[f] == 0) continue;  // |r| < t_far only, see rdf_fast_setup
         if (boxes != nullptr && p.cull_on && !tp.diagonal) {
           // short cutoff: the two tiles' boxes are further apart than any pair that counts
           const float *fb = boxes + static_cast<int64_t>(f) * 5 * n_tiles * 6;
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
   if (!kLiteral && only_unwrapped) {
     // complement of the fast kernel: most launches have nothing to do here
     bool any = false;
-    for (int f = f_begin; f < f_end; ++f) any = any || (frame_wrapped[f] != 2);
+    for (int f = f_begin; f < f_end; ++f) any = any || (frame_wrapped[f] == 0);
     if (!any) return;
   }
 
@@ -1193,7 +1196,7 @@ __global__ __launch_bounds__(kTile) void rdf_tile_kernel(
       const float *yj = xj + n_pad;
       const float *zj = yj + n_pad;
       const bool wrapped = frame_wrapped[f] != 0;
-      if (only_unwrapped && frame_wrapped[f] == 2) continue;  // the fast kernel took it
+      if (only_unwrapped && frame_wrapped[f] != 0) continue;  // the fast kernel took it
       if (tp.diagonal) {
         if (wrapped)
           table_tile_loop<true, true>(xi, yi, zi, xj, yj, zj, hist, thr, p, tid);
@@ -1347,17 +1350,19 @@ std::vector<uint16_t> hilbert_tables() {
 
 // Parameters of the fast kernel and the bound that makes it exact.
 //
-// For a pair in a compact frame (|r_c| <= L_c in every component) let pos_lit =
-// double(d_lit) / step be the position the literal sequence bins, and P the number the
-// fast loop forms before adding 2^k + shift (fast_position_bits).  With u = 2^-24 and
-// h = L_c / 2 (exact):
-//   * per component |m - m_lit| <= u L_c.  h - ||r| - h| equals min(|r|, L_c - |r|) in
-//     exact arithmetic.  Of the fast path's two subtractions at most one rounds: for
-//     |r| < h/2, t = |r| - h rounds (by at most u |t| <= u h) and then h/2 < |t| <= h
-//     makes m = h - |t| exact; for h/2 <= |r| <= 2h, t is exact (both operands within a
-//     factor two) and m rounds by at most u |m| <= u h.  The literal value is |r| itself
-//     or L_c - |r| rounded by at most u h.  Hence the two exact norms differ by at most
-//     A = u |L|;
+// For a pair of a frame whose coordinate differences stay below t_far (|r_c| < 1.5 L_c,
+// where the literal rint(r / L) is at most one) let pos_lit = double(d_lit) / step be the
+// position the literal sequence bins, and P the number the fast loop forms before adding
+// 2^k + shift (fast_position_bits).  With u = 2^-24 and h = L_c / 2 (exact):
+//   * per component |m - m_lit| <= u L_c.  h - ||r| - h| equals the magnitude of the
+//     minimum image, min(|r|, |L_c - |r||), in exact arithmetic.  Of the fast path's two
+//     subtractions at most one rounds: for |r| < h/2, t = |r| - h rounds (by at most
+//     u |t| <= u h) and then h/2 < |t| <= h makes m = h - |t| exact; for h/2 <= |r| <= 2h,
+//     t is exact (both operands within a factor two) and m rounds by at most u |m| <= u h;
+//     for 2h < |r| < 3h, t rounds by at most u |t| <= u L_c and h < |t| <= 2h makes m
+//     exact.  The literal value is r itself or r -+ L_c, which is exact too (operands
+//     within a factor two) or rounds by at most u h.  Hence the two exact norms differ by
+//     at most A = u |L|;
 //   * the fast squared sum carries three roundings, (1 + u)^3, so its root 1.5 u, and
 //     v_sqrt_f32 is good to one ulp (2 u); the literal squared sum likewise 1.5 u after
 //     the root and sqrtf adds u; the scale nbins / cutoff is rounded once (u):

@@ -247,6 +247,35 @@ def pairs_near_bin_edges(box, cutoff, nbins, edges, per_edge, rng, through_wrap=
             np.concatenate([out_j, xj[fits]]).astype(F32))
 
 
+def pairs_of_spread_frames(box, n, rng):
+    """Pairs of a frame that spreads over up to 1.5 box lengths (atoms that left the box
+    since they were last wrapped): coordinates in [-L/4, 5L/4], half of the pairs with
+    differences within a few float32 steps of 0, L/2, L, 5L/4 and 3L/2 per component (at
+    3L/2 the literal rint reaches 2; a frame the kernel takes stays below it), half uniform."""
+    box = np.asarray(box, F32)
+    xi = np.empty((n, 3), F32)
+    xj = np.empty((n, 3), F32)
+    for c in range(3):
+        length = box[c]
+        anchors = np.array([0.0, length / 2, length, 1.25 * length, 1.5 * length], F32)
+        base = rng.choice(np.array([-length / 4, 0.0, length / 4], F32), n)
+        other = (base + rng.choice(anchors, n)).astype(F32)
+        other = _nudge(other, rng.integers(-4, 5, n))
+        top = np.nextafter(F32(1.25) * length, F32(0.0))   # differences stay below 3L/2
+        other = np.minimum(other, top).astype(F32)
+        uniform = rng.random(n) < 0.5
+        base = np.where(uniform, (rng.random(n).astype(F32) * F32(1.5) - F32(0.25)) * length,
+                        base).astype(F32)
+        other = np.where(uniform, (rng.random(n).astype(F32) * F32(1.5) - F32(0.25)) * length,
+                         other).astype(F32)
+        other = np.minimum(other, top).astype(F32)
+        base = np.minimum(base, top).astype(F32)
+        swap = rng.random(n) < 0.5
+        xi[:, c] = np.where(swap, other, base)
+        xj[:, c] = np.where(swap, base, other)
+    return xi, xj
+
+
 def uniform_pairs(box, n, rng):
     box = np.asarray(box, F32)
     xi = (rng.random((n, 3)).astype(F32) * box).astype(F32)

@@ -354,3 +354,48 @@ def test_sorted_frames_random_geometries(gpu, monkeypatch, seed):
                             cutoff, nbins, strict=strict)
     np.testing.assert_array_equal(got, ref)
     assert ref.sum() > 0
+
+
+@pytest.mark.parametrize("case", ["a_little_outside", "a_quarter_box_outside", "mixed_frames"])
+def test_frames_that_left_the_box_a_little(gpu, monkeypatch, case):
+    """Frames whose atoms have moved out of the box since they were last wrapped spread over
+    more than one box length; while every coordinate difference stays below the point where
+    the literal rule would shift by two box lengths (about 1.5 L) the default kernel takes
+    them, sorted like the others.  Atoms up to 0.5 and up to a quarter of a box length outside,
+    and a block of frames of all three kinds (inside, a little outside, boxes away: the last
+    go to the table kernel); sorted and unsorted, against the C oracle."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n_per_species, frames = [3100, 2700], 4
+    box = np.array([38.0, 38.0, 38.0], np.float32)
+    cutoff, nbins = np.float32(18.9), 1890
+    pos = [(rng.random((n, frames, 3)) * box).astype(np.float32) for n in n_per_species]
+    if case == "a_little_outside":
+        for p in pos:
+            p += rng.normal(scale=0.15, size=p.shape).astype(np.float32)
+    elif case == "a_quarter_box_outside":
+        for p in pos:
+            p[:] = ((rng.random(p.shape) * 1.49 - 0.245) * box).astype(np.float32)
+    else:
+        for p in pos:
+            p[:, 1] += rng.normal(scale=0.2, size=p[:, 1].shape).astype(np.float32)
+            p[::7, 2, 0] += np.float32(3.0) * box[0]                    # frame 2: boxes away
+            p[:, 3] = ((rng.random(p[:, 3].shape) * 1.45 - 0.2) * box).astype(np.float32)
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, list(box), cutoff, nbins)
+    for unfold in ("1", "0"):
+        monkeypatch.setenv("MDX_RDF_UNFOLD", unfold)
+        monkeypatch.setenv("MDX_RDF_CULL", "0")
+        eng = gpu.RdfEngine(n_per_species, list(box), cutoff, nbins)
+        eng.accumulate(pos)
+        got = eng.read()
+        eng.close()
+        np.testing.assert_array_equal(got, ref, err_msg=f"unfold={unfold}")
+    # short cutoff with skipping on the same frames
+    monkeypatch.setenv("MDX_RDF_UNFOLD", "1")
+    monkeypatch.setenv("MDX_RDF_CULL", "1")
+    short, short_bins = np.float32(5.5), 550
+    eng = gpu.RdfEngine(n_per_species, list(box), short, short_bins)
+    eng.accumulate(pos)
+    got = eng.read()
+    eng.close()
+    ref = c_oracle.rdf_hist(np.concatenate(pos, 0), n_per_species, list(box), short, short_bins)
+    np.testing.assert_array_equal(got, ref)

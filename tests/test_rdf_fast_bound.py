@@ -6,8 +6,9 @@ position lies within ``edge_units`` grid steps above a bin edge; the library der
 position (mdx_rdf.hip ``rdf_fast_setup``).  Here the kernel's arithmetic, restated in NumPy
 float32 with the hardware square root allowed to be one step off either way
 (oracle/rdf_fast_model.py), runs on pairs built to sit on the worst places -- coordinate
-differences at 0, L/2 and L, distances within a few float32 steps of bin edges and of
-the cutoff, long thin boxes, bin counts up to the kernel's limit -- with the constants the
+differences at 0, L/2 and L (and up to 3L/2 for frames whose atoms have left the box a
+little), distances within a few float32 steps of bin edges and of the cutoff, long thin
+boxes, bin counts up to the kernel's limit -- with the constants the
 library itself reports through ``mdx_rdf_fast_plan`` (a host-only call: no GPU needed).
 The literal side follows radial_distribution_function.py:647-689, linalg.py:84-99 and the
 ``tf.histogram_fixed_width`` CPU rule.
@@ -71,6 +72,7 @@ def test_fast_kernel_decisions_equal_the_literal_rule(box, cutoff, nbins):
         model.pairs_near_bin_edges(box, cutoff32, nbins, [nbins - 1, 1], 10_000, rng,
                                    through_wrap=False),
         model.uniform_pairs(box, 200_000, rng),
+        model.pairs_of_spread_frames(box, 200_000, rng),
     ]
     worst_high = 0.0
     unfolded = 0
