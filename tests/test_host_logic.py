@@ -501,3 +501,34 @@ def test_cached_read_maps_follow_writes_and_resizes(tmp_path):
     assert len([k for k in sdb._READ_MAPS if k[0].startswith(str(tmp_path))]) == 1
     sdb.release_read_maps()
     assert not sdb._READ_MAPS
+
+
+def test_bench_estimate_of_fold_free_components():
+    """bench.py prices the RDF loop with the share of (64-atom group pair, component)
+    combinations that need no minimum-image fold, estimated on the host from one frame:
+    the groups' boxes must really bound their atoms' differences by half a box length
+    wherever the estimate says so, and for the benchmark geometry about half of them do."""
+    import importlib.util
+    import pathlib
+
+    spec = importlib.util.spec_from_file_location(
+        "bench_module", pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(3)
+    frame = [(rng.random((4999, 3)) * 65.0).astype(np.float32) for _ in range(2)]
+    out = bench.fold_free_share(frame, 65.0)
+    assert 0.45 < out["share"] < 0.65
+    # Hilbert ranks of a 2 x 2 x 2 grid: a permutation in which consecutive cells touch
+    cells = np.array([[x, y, z] for z in range(2) for y in range(2) for x in range(2)])
+    rank = bench._hilbert_rank(cells, 1)
+    assert sorted(rank.tolist()) == list(range(8))
+    walk = cells[np.argsort(rank)]
+    assert (np.abs(np.diff(walk, axis=0)).sum(axis=1) == 1).all()
+    cells3 = np.array([[x, y, z] for z in range(8) for y in range(8) for x in range(8)])
+    rank3 = bench._hilbert_rank(cells3, 3)
+    assert sorted(rank3.tolist()) == list(range(512))
+    assert (np.abs(np.diff(cells3[np.argsort(rank3)], axis=0)).sum(axis=1) == 1).all()
+    # a dilute species (groups as wide as the box) has nothing to leave out
+    sparse = [(rng.random((130, 3)) * 65.0).astype(np.float32)]
+    assert bench.fold_free_share(sparse + sparse, 65.0)["share"] < 0.25
