@@ -437,6 +437,7 @@ def main() -> None:
             "frames_per_rank": steps * fps,
             "parallelism": parallelism,
             "kernel": args.kernel,
+            "fold_free_loop_variants": unfolded is not None,
         },
         "roofline": roofline,
         "valu": valu,
