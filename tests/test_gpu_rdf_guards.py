@@ -317,7 +317,8 @@ def test_sorted_frames_random_geometries(gpu, monkeypatch, seed):
     """Random systems on the sorted-frame path: one to three species of 2 100 to 5 200
     atoms, cubic and rectangular boxes, cutoffs from a tenth of the shortest edge to just
     below half of it, 50 to 6 000 bins, both mask conventions, uniform, clustered and
-    lattice-like positions.  Sorting and the fold-free loop variants are switched on whatever
+    lattice-like positions, every fourth case with a frame whose atoms lie a little outside
+    the box.  Sorting and the fold-free loop variants are switched on whatever
     the geometry (the library's own choice would leave out the long boxes), the skipping of
     what the boxes put out of reach for every other case; against the C oracle, bit for bit."""
     monkeypatch.setenv("MDX_RDF_UNFOLD", "1")
@@ -344,6 +345,9 @@ def test_sorted_frames_random_geometries(gpu, monkeypatch, seed):
         else:
             spacing = box / np.float32(32.0)
             p = rng.integers(0, 32, (n, 1, 3)) * spacing + rng.random((n, 2, 3)) * 1e-3
+        if seed % 4 == 3:
+            # atoms that have left the box since they were last wrapped (second frame only)
+            p[:, 1] += rng.normal(scale=0.03 * shortest, size=p[:, 1].shape)
         pos.append(np.ascontiguousarray(p, np.float32))
     eng = gpu.RdfEngine(n_per_species, [float(b) for b in box], cutoff, nbins,
                         strict_reference_masks=strict)
