@@ -352,49 +352,50 @@ __global__ __launch_bounds__(256) void rdf_sort_kernel(
       quarter_box(t, v);
     }
   } else {
-  for (int i0 = w_begin; i0 < w_end; i0 += 64) {
-    const int i = i0 + lane;
-    const bool valid = i < w_end;
-    const uint32_t cell = valid ? cell_of(i) : 0xFFFFFFFFu;
-    // The wave's next free position in the lane's cell, before and after the group has
-    // taken its places there (the wave's LDS operations keep their order).  A lane alone in
-    // its cell -- the rule, with thousands of cells -- owns the one place; lanes that share
-    // a cell are ranked by lane with ballots, lowest first.
-    uint32_t first = 0u, taken = 0u;
-    if (valid) {
-      first = own[cell];
-      atomicAdd(&own[cell], 1u);
-      taken = own[cell] - first;
-    }
-    uint32_t dst = first;
-    unsigned long long remaining = __ballot(taken > 1u);
+    for (int i0 = w_begin; i0 < w_end; i0 += 64) {
+      const int i = i0 + lane;
+      const bool valid = i < w_end;
+      const uint32_t cell = valid ? cell_of(i) : 0xFFFFFFFFu;
+      // The wave's next free position in the lane's cell, before and after the group has
+      // taken its places there (the wave's LDS operations keep their order).  A lane alone in
+      // its cell -- the rule, with thousands of cells -- owns the one place; lanes that share
+      // a cell are ranked by lane with ballots, lowest first.
+      uint32_t first = 0u, taken = 0u;
+      if (valid) {
+        first = own[cell];
+        atomicAdd(&own[cell], 1u);
+        taken = own[cell] - first;
+      }
+      uint32_t dst = first;
+      unsigned long long remaining = __ballot(taken > 1u);
 #ifdef MDX_TIMING_SWITCHES
-    if (p.timing_mask == 100 || p.timing_mask == 101) { remaining = 0ull; dst = i; }
+      if (p.timing_mask == 100 || p.timing_mask == 101) { remaining = 0ull; dst = i; }
 #endif
-    while (remaining != 0ull) {
-      const int leader = __builtin_ctzll(remaining);
-      const uint32_t c0 = static_cast<uint32_t>(
-          __builtin_amdgcn_readlane(static_cast<int>(cell), leader));
-      const unsigned long long same = __ballot(cell == c0);
-      if (cell == c0) dst = first + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
-      remaining &= ~same;
-    }
-    if (valid) {
+      while (remaining != 0ull) {
+        const int leader = __builtin_ctzll(remaining);
+        const uint32_t c0 = static_cast<uint32_t>(
+            __builtin_amdgcn_readlane(static_cast<int>(cell), leader));
+        const unsigned long long same = __ballot(cell == c0);
+        if (cell == c0)
+          dst = first + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1ull)));
+        remaining &= ~same;
+      }
+      if (valid) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Y[c * n_pad + dst] = X[c * n_pad + i];
+        for (int c = 0; c < 3; ++c) Y[c * n_pad + dst] = X[c * n_pad + i];
+      }
     }
-  }
-  for (int i = sp.used + tid; i < slots; i += 256)
-    for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
+    for (int i = sp.used + tid; i < slots; i += 256)
+      for (int c = 0; c < 3; ++c) Y[c * n_pad + i] = nan;
 #ifdef MDX_TIMING_SWITCHES
-  if (p.timing_mask == 101) return;
+    if (p.timing_mask == 101) return;
 #endif
-  __syncthreads();  // the block reads back what it wrote
-  for (int t = 0; t < sp.tiles; ++t) {
-    float v[3];
-    for (int c = 0; c < 3; ++c) v[c] = Y[c * n_pad + t * kTile + tid];
-    quarter_box(t, v);
-  }
+    __syncthreads();  // the block reads back what it wrote
+    for (int t = 0; t < sp.tiles; ++t) {
+      float v[3];
+      for (int c = 0; c < 3; ++c) v[c] = Y[c * n_pad + t * kTile + tid];
+      quarter_box(t, v);
+    }
   }
   __syncthreads();
   for (int t = tid; t < sp.tiles; t += 256) {
@@ -768,7 +769,8 @@ __device__ __forceinline__ void fast_j_range(
     uint32_t masks, float xi, float yi, float zi,
     const float *__restrict__ xj, const float *__restrict__ yj, const float *__restrict__ zj,
     uint32_t *__restrict__ hist, uint16_t *__restrict__ queue, const float *__restrict__ g_thr,
-    const RdfParams &p, const FastRegs &r, int tid, float hx, float hy, float hz, float scale, float magic,
+    const RdfParams &p, const FastRegs &r, int tid, float hx, float hy, float hz, float scale,
+    float magic,
     uint32_t addr_mask, uint32_t frac_mask, uint32_t one) {
   const uint32_t shift = r.shift;
   const uint32_t edge = p.fast_edge_units;
@@ -862,7 +864,8 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p,
+    const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one) {
   const int j_begin = kDiag ? __builtin_amdgcn_readfirstlane(tid & ~63) : 0;
@@ -921,7 +924,8 @@ template <bool kDiag>
 __device__ __forceinline__ void fast_tile_loop_sorted(
     float xi, float yi, float zi, const float *__restrict__ xj, const float *__restrict__ yj,
     const float *__restrict__ zj, int j_count, uint32_t *__restrict__ hist,
-    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p, const FastRegs &r, int tid,
+    uint16_t *__restrict__ queue, const float *__restrict__ g_thr, const RdfParams &p,
+    const FastRegs &r, int tid,
     float hx, float hy, float hz, float scale, float magic, uint32_t addr_mask,
     uint32_t frac_mask, uint32_t one, const float *__restrict__ ibox,
     const float *__restrict__ jboxes) {
@@ -955,17 +959,20 @@ __device__ __forceinline__ void fast_tile_loop_sorted(
     if (kDiag && q == wave) {
       // the wave's own quarter: one box on both sides, as a rule narrower than half the box
       if (mask == 0)
-        fast_j_range<true, 0>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
-                              hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+        fast_j_range<true, 0>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj,
+                              hist, queue, g_thr, p, r, tid, hx, hy, hz, scale, magic, addr_mask,
+                              frac_mask, one);
       else
-        fast_j_range<true, 7>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid,
-                              hx, hy, hz, scale, magic, addr_mask, frac_mask, one);
+        fast_j_range<true, 7>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj,
+                              hist, queue, g_thr, p, r, tid, hx, hy, hz, scale, magic, addr_mask,
+                              frac_mask, one);
       continue;
     }
 #define MDX_FOLD_CASE(M)                                                                     \
   case M:                                                                                    \
-    fast_j_range<false, M>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, hist, queue, g_thr, p, r, tid, \
-                           hx, hy, hz, scale, magic, addr_mask, frac_mask, one);            \
+    fast_j_range<false, M>(lo, hi, j_end, nx, ny, nz, count, masks, xi, yi, zi, xj, yj, zj, \
+                           hist, queue, g_thr, p, r, tid, hx, hy, hz, scale, magic,         \
+                           addr_mask, frac_mask, one);                                      \
     break;
     switch (mask) {
       MDX_FOLD_CASE(0)
