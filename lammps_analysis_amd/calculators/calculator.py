@@ -25,52 +25,55 @@ log = logging.getLogger(__name__)
 def call(func):
     """Decorator of ``Calculator.__call__`` (see module docstring)."""
 
+    def stored_or_computed(calculator, args, kwargs) -> db.Computation:
+        """The computation that belongs to the arguments of this call: the one on record,
+        or a fresh run that is put on record first."""
+        func(calculator, *args, **kwargs)
+        on_record = calculator.get_computation_data()
+        if on_record is not None:
+            return on_record
+        calculator.prepare_db_entry()
+        calculator.save_computation_args()
+        calculator.run_analysis()
+        calculator.save_db_data()
+        # a run may fill defaults into the stored arguments; the user's own values go back
+        # in so that the look-up finds what was just saved
+        func(calculator, *args, **kwargs)
+        return calculator.get_computation_data()
+
     @functools.wraps(func)
     def inner(self, *args, **kwargs) -> Union[db.Computation, Dict[str, db.Computation]]:
-        return_dict = self.experiment is None
-        out = {}
+        per_experiment = {}
         for experiment in self.experiments:
-            cls = self.__class__(experiment=experiment)
-            func(cls, *args, **kwargs)
-            data = cls.get_computation_data()
-            if data is None:
-                cls.prepare_db_entry()
-                cls.save_computation_args()
-                cls.run_analysis()
-                cls.save_db_data()
-                # run_analysis may have replaced defaults inside args; restore the
-                # user's values so that the lookup matches what was saved
-                func(cls, *args, **kwargs)
-                data = cls.get_computation_data()
-            out[cls.experiment.name] = data
-        return out if return_dict else out[self.experiment.name]
+            fresh = type(self)(experiment=experiment)
+            per_experiment[fresh.experiment.name] = stored_or_computed(fresh, args, kwargs)
+        if self.experiment is None:          # called through a project: all of them
+            return per_experiment
+        return per_experiment[self.experiment.name]
 
     return inner
 
 
+# attributes every calculator starts with (calculator.py:151-317 of the reference names them)
+_CALCULATOR_DEFAULTS = dict(
+    plot=False, plotter=None, x_label=None, y_label=None,
+    analysis_name=None, result_keys=None, result_series_keys=None,
+    selected_species=None, system_property=False, experimental=False,
+    time=None, prefactor=None)
+
+
 class Calculator(CalculatorDatabase):
-    """Attributes shared by all calculators (calculator.py:151-317 of the reference)."""
+    """What all calculators share: the experiment(s) they work on, the result keys, the
+    ``@call`` protocol's hooks."""
 
     def __init__(self, experiment=None, experiments: List = None):
         super().__init__(experiment)
         self.experiment = experiment
-        self.experiments = experiments
-        if self.experiment is not None:
-            self.experiments = [self.experiment]
-        self.plot = False
-        self.result_keys = None
-        self.result_series_keys = None
-        self.analysis_name = None
-        self.selected_species = None
-        self.system_property = False
-        self.experimental = False
-        self.time = None
-        self.prefactor = None
-        self._dtype = np.float64
-        self.plotter = None
-        self.x_label = None
-        self.y_label = None
+        self.experiments = [experiment] if experiment is not None else experiments
+        for name, value in _CALCULATOR_DEFAULTS.items():
+            setattr(self, name, value)
         self.plot_array = []
+        self._dtype = np.float64
 
     @property
     def dtype(self):
