@@ -148,8 +148,8 @@ def parse_args():
                          "atom-pair tiles (strong scaling, configs[3])")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames per step; 0 = the configuration's 100 000 frames divided "
-                         "over the timed steps (nacl) or 16 (water)")
-    ap.add_argument("--cpu-frames", type=int, default=24,
+                         "over the timed steps (nacl) or 64 (water)")
+    ap.add_argument("--cpu-frames", type=int, default=240,
                     help="frames of the CPU-baseline sample (0 disables it)")
     ap.add_argument("--gk-frames", type=int, default=100000,
                     help="frames of the Green-Kubo side measurement (0 disables it)")
